@@ -1,0 +1,231 @@
+/*
+ * orbx -- C ABI of the MI355X (gfx950) ORB front-end: ORB extraction and Hamming
+ * descriptor matching as HIP kernels.  This is the drop-in boundary for the two C++
+ * classes the reference links into libORB_SLAM3.so:
+ *
+ *   ORB_SLAM3::ORBextractor   include/ORBextractor.h:42-121, src/ORBextractor.cc
+ *   ORB_SLAM3::ORBmatcher     include/ORBmatcher.h:34-226,   src/ORBmatcher.cc
+ *   + the Frame members that are part of the same data-parallel path
+ *     (Frame::ComputeStereoMatches src/Frame.cc:962-1133,
+ *      Frame::ComputeStereoFishEyeMatches src/Frame.cc:1286-1338,
+ *      Frame::AssignFeaturesToGrid / GetFeaturesInArea src/Frame.cc:468-506, :792-858).
+ *
+ * Conventions
+ *  - plain C: opaque handles, POD structs, pointers + sizes; no exceptions cross it;
+ *  - every function returns an orbx_status (0 = OK, negative = error) unless noted;
+ *    orbx_last_error() gives the message of the calling thread's last failure;
+ *  - "host" entry points take host pointers and are synchronous; "_device" entry points
+ *    take device pointers, enqueue on the given hipStream_t (passed as void*; NULL = the
+ *    handle's own stream) and do not synchronise;
+ *  - one handle may be used by one thread at a time; distinct handles are independent
+ *    (the reference runs one extractor per camera thread, Frame.cc:143-147);
+ *  - orbx_keypoint has the memory layout of cv::KeyPoint (28 bytes) and descriptors are
+ *    row-major N x 32 bytes, so std::vector<cv::KeyPoint>::data() and cv::Mat::data can be
+ *    passed straight through.
+ */
+#ifndef ORBX_H_
+#define ORBX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int orbx_status;
+enum {
+    ORBX_OK = 0,
+    ORBX_ERR_INVALID = -1,   /* bad argument / unsupported geometry                      */
+    ORBX_ERR_CAPACITY = -2,  /* a caller- or handle-provided capacity was too small      */
+    ORBX_ERR_HIP = -3,       /* a HIP runtime call failed (no device, out of memory ...) */
+    ORBX_ERR_EMPTY = -4      /* empty image (the reference's operator() returns -1)      */
+};
+
+/* cv::KeyPoint layout. */
+typedef struct orbx_keypoint {
+    float x, y;      /* pt, level-0 pixel coordinates                          */
+    float size;      /* (int)(31 * scale[octave])                              */
+    float angle;     /* degrees, [0, 360)                                      */
+    float response;  /* FAST score                                             */
+    int octave;      /* pyramid level                                          */
+    int class_id;    /* always -1                                              */
+} orbx_keypoint;
+
+/* cv::Rect2i layout (ORBextractor::mvDynamicArea, ORBextractor.h:95-96). */
+typedef struct orbx_rect { int x, y, width, height; } orbx_rect;
+
+/* Two nearest neighbours of one query (cv::DMatch pair of knnMatch(k=2)).
+ * Missing neighbours have idx = -1 and dist = INT32_MAX. */
+typedef struct orbx_match2 { int32_t idx0, dist0, idx1, dist1; } orbx_match2;
+
+/* Constructor arguments of ORBextractor (ORBextractor.cc:477-479) plus buffer sizing. */
+typedef struct orbx_params {
+    int nfeatures;
+    float scale_factor;
+    int nlevels;
+    int ini_th_fast;
+    int min_th_fast;
+    int max_width;    /* largest image the handle will see                    */
+    int max_height;
+    int max_batch;    /* frames per batched call (>= 1)                       */
+    int device;       /* HIP device ordinal, -1 = current device              */
+} orbx_params;
+
+typedef struct orbx_extractor orbx_extractor;
+
+const char* orbx_last_error(void);
+/* Number of visible HIP devices, or a negative status. */
+int orbx_device_count(void);
+
+/* ---------------------------------------------------------------- extractor -------- */
+
+/* ORBextractor::ORBextractor (ORBextractor.cc:477-536). */
+orbx_status orbx_extractor_create(const orbx_params* params, orbx_extractor** out);
+void orbx_extractor_destroy(orbx_extractor* ex);
+
+/* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (ORBextractor.h:73-91) and mnFeaturesPerLevel;
+ * each array has nlevels entries; any pointer may be NULL. */
+orbx_status orbx_extractor_tables(const orbx_extractor* ex, float* scale, float* inv_scale,
+                                  float* sigma2, float* inv_sigma2, int* features_per_level);
+
+/* Largest number of keypoints one frame can yield (>= nfeatures); size output buffers
+ * with it. */
+int orbx_extractor_max_keypoints(const orbx_extractor* ex);
+
+/* ORBextractor::operator() (ORBextractor.cc:1271-1399) for one host image.
+ * image: 8-bit single channel, `stride` bytes per row.  lap0/lap1 = vLappingArea.
+ * dyn/ndyn = mvDynamicArea (may be NULL/0).  keypoints/descriptors: caller buffers of
+ * `capacity` rows.  *n_out = number of keypoints, *mono_index_out = the return value of
+ * operator().  Returns ORBX_ERR_EMPTY for a NULL / zero-sized image. */
+orbx_status orbx_extract(orbx_extractor* ex, const uint8_t* image, int width, int height, ptrdiff_t stride,
+                         int lap0, int lap1, const orbx_rect* dyn, int ndyn,
+                         orbx_keypoint* keypoints, uint8_t* descriptors, int capacity,
+                         int* n_out, int* mono_index_out);
+
+/* Batched operator() over n_frames host images of identical size (one call = one
+ * pass of every kernel over the whole batch).  images[i] points at frame i.  Outputs are
+ * n_frames x capacity rows; n_out / mono_index_out have n_frames entries. */
+orbx_status orbx_extract_batch(orbx_extractor* ex, const uint8_t* const* images, int n_frames,
+                               int width, int height, ptrdiff_t stride, int lap0, int lap1,
+                               orbx_keypoint* keypoints, uint8_t* descriptors, int capacity,
+                               int* n_out, int* mono_index_out);
+
+/* Same, device resident and asynchronous: d_images = n_frames images, `frame_stride`
+ * bytes apart; d_keypoints / d_descriptors = n_frames x capacity rows; d_counts =
+ * n_frames x {n, mono_index}.  Check orbx_extract_status() after synchronising. */
+orbx_status orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, int n_frames,
+                                      int width, int height, ptrdiff_t row_stride, ptrdiff_t frame_stride,
+                                      int lap0, int lap1, const orbx_rect* dyn_host, int ndyn,
+                                      orbx_keypoint* d_keypoints, uint8_t* d_descriptors, int capacity,
+                                      int* d_counts, void* stream);
+
+/* After the stream of the last batched device call has been synchronised: ORBX_OK, or
+ * ORBX_ERR_CAPACITY when an internal candidate / output buffer overflowed (results of
+ * that call are then invalid; the handle has grown its buffers, call again). */
+orbx_status orbx_extract_status(orbx_extractor* ex);
+
+/* ORBextractor::mvImagePyramid (ORBextractor.h:93) of the last call: copies level
+ * `level` of batch slot `frame` (borderless, w x h, tightly packed) to a host buffer of
+ * `capacity` bytes.  out may be NULL to query the size only. */
+orbx_status orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t* out, size_t capacity,
+                               int* width, int* height);
+/* Device view of the same level: pointer and row pitch in bytes. */
+orbx_status orbx_pyramid_level_device(orbx_extractor* ex, int frame, int level, const uint8_t** d_ptr,
+                                      int* width, int* height, ptrdiff_t* pitch);
+
+/* Stage taps for tests (device results copied to the host, last call, batch slot `frame`):
+ * FAST candidates of one level after the per-cell round trip, as rows of
+ * {x, y, response, order_key} floats / ints (order_key sorts them in the reference's
+ * cell-by-cell emission order); returns the count through *n_out. */
+orbx_status orbx_debug_level_candidates(orbx_extractor* ex, int frame, int level, float* xyr, uint32_t* order_key,
+                                        int capacity, int* n_out);
+/* Keypoints of one level after quadtree distribution, in node-list order, level coordinates. */
+orbx_status orbx_debug_level_keypoints(orbx_extractor* ex, int frame, int level, float* xyr, int capacity,
+                                       int* n_out);
+
+/* ---------------------------------------------------------------- matcher ---------- */
+
+/* ORBmatcher::DescriptorDistance (ORBmatcher.cc:2141-2157) for n pairs: out[i] =
+ * popcount(a[i] xor b[i]) over 256 bits.  Host pointers. */
+orbx_status orbx_descriptor_distance(const uint8_t* a, const uint8_t* b, int n, int* out);
+
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(query, train, 2) (Frame.cc:46, :1309): the two
+ * smallest distances per query, ties towards the lower train index.  Host pointers. */
+orbx_status orbx_hamming_knn2(const uint8_t* query, int n_query, const uint8_t* train, int64_t n_train,
+                              orbx_match2* out);
+/* Device-resident variant; train indices are reported as base_index + row, so a shard of a
+ * larger map reports global indices.  `workspace` must hold orbx_knn2_workspace_bytes(). */
+size_t orbx_knn2_workspace_bytes(int n_query, int64_t n_train);
+orbx_status orbx_hamming_knn2_device(const uint8_t* d_query, int n_query, const uint8_t* d_train, int64_t n_train,
+                                     int64_t base_index, orbx_match2* d_out, void* d_workspace, size_t workspace_bytes,
+                                     void* stream);
+/* Merge n_parts per-shard results (n_parts x n_query, shard-major) into the global top-2,
+ * lexicographic on (dist, idx): the step after an all-gather of per-GPU shards. */
+orbx_status orbx_knn2_merge_device(const orbx_match2* d_parts, int n_parts, int n_query, orbx_match2* d_out,
+                                   void* stream);
+
+/* Frame::ComputeStereoMatches (Frame.cc:962-1133) on the pyramids held by two extractor
+ * handles (batch slot `frame` of each; left/right keypoints as returned by orbx_extract*).
+ * mbf = baseline * fx, mb = baseline (the reference's minZ; maxD = mbf / mb).
+ * u_right / depth: n_left floats, -1 where no match.  Host pointers, synchronous. */
+orbx_status orbx_stereo_match(orbx_extractor* left, orbx_extractor* right, int frame,
+                              const orbx_keypoint* kps_left, const uint8_t* desc_left, int n_left,
+                              const orbx_keypoint* kps_right, const uint8_t* desc_right, int n_right,
+                              float mbf, float mb, float* u_right, float* depth);
+/* Batched device variant over the frames of the last orbx_extract_batch_device calls on
+ * both handles: inputs are the d_keypoints / d_descriptors / d_counts buffers of those
+ * calls (same capacity); outputs n_frames x capacity floats. */
+orbx_status orbx_stereo_match_batch_device(orbx_extractor* left, orbx_extractor* right, int n_frames,
+                                           const orbx_keypoint* d_kps_left, const uint8_t* d_desc_left,
+                                           const int* d_counts_left,
+                                           const orbx_keypoint* d_kps_right, const uint8_t* d_desc_right,
+                                           const int* d_counts_right, int capacity,
+                                           float mbf, float mb, float* d_u_right, float* d_depth, void* stream);
+
+/* Windowed projection search core shared by ORBmatcher::SearchByProjection
+ * (ORBmatcher.cc:42-216) and its siblings: for every query (projected map point) the
+ * keypoints returned by Frame::GetFeaturesInArea(x, y, radius, min_level, max_level)
+ * (Frame.cc:792-858) over the 64 x 48 grid built by AssignFeaturesToGrid with the image
+ * bounds {min_x, max_x, min_y, max_y}, in the reference's (cell-x, cell-y, insertion)
+ * order, each with its Hamming distance to the query descriptor.  A candidate is dropped
+ * when uright != NULL, uright[idx] > 0 and |query_xr - uright[idx]| > radius (the stereo
+ * gate of ORBmatcher.cc:92-97).  Output is CSR: cand_offset[n_query+1], then cand_idx /
+ * cand_dist with `capacity` entries; *n_cand_out = total (ORBX_ERR_CAPACITY if larger).
+ * Host pointers. */
+typedef struct orbx_query {
+    float x, y;         /* projection                                          */
+    float xr;           /* projected right-image u (stereo gate), unused if no uright */
+    float radius;       /* search radius in pixels                             */
+    int min_level;      /* as GetFeaturesInArea: -1 / <=0 and max<0 = no check */
+    int max_level;
+} orbx_query;
+orbx_status orbx_window_candidates(const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps,
+                                   float min_x, float max_x, float min_y, float max_y,
+                                   const orbx_query* queries, const uint8_t* query_desc, int n_query,
+                                   int* cand_offset, int* cand_idx, int* cand_dist, int capacity, int* n_cand_out);
+
+/* ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) for the mono /
+ * rectified case (ORBmatcher.cc:42-147): device candidates + the greedy in-order resolve
+ * (best / second best with levels, TH_HIGH = 100, ratio test only when both are on the same
+ * level).  taken[idx] != 0 marks keypoints that already hold a map point with observations;
+ * accepted matches set it.  match_out[q] = keypoint index or -1.  Returns the number of
+ * matches through *n_matches. */
+orbx_status orbx_search_by_projection(const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps,
+                                      float min_x, float max_x, float min_y, float max_y,
+                                      const orbx_query* queries, const uint8_t* query_desc, int n_query,
+                                      float nn_ratio, uint8_t* taken, int* match_out, int* n_matches);
+
+/* Distance core of ORBmatcher::SearchForTriangulation (ORBmatcher.cc:1051-1167): for two
+ * keyframes whose descriptors are bucketed by shared vocabulary node (CSR: off[n_buckets+1]
+ * into idx arrays), for every idx1 the LAST idx2 of the same bucket with the smallest
+ * distance <= TH_LOW (50); best_idx2 = -1 when none.  Host pointers. */
+orbx_status orbx_bucket_best(const uint8_t* desc1, int n_desc1, const int* idx1, const int* off1,
+                             const uint8_t* desc2, int n_desc2, const int* idx2, const int* off2, int n_buckets,
+                             int* best_idx2, int* best_dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H_ */
