@@ -581,7 +581,7 @@ struct Extractor {
             Plane blurred;
             gaussian7_u8(pyr[l], blurred);
             const float scale = sf[l];
-            for (KeyPt& kp : kps) {
+            for (KeyPt kp : kps) {   // by value: the per-level list keeps level coordinates
                 uint8_t d[32];
                 describe(blurred, kp, d);
                 if (l != 0) { kp.x *= scale; kp.y *= scale; }

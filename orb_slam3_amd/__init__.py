@@ -1,0 +1,8 @@
+"""orb_slam3_amd: MI355X (gfx950) ORB front-end -- ORB extraction and Hamming descriptor
+matching as HIP kernels behind a C ABI (include/orbx.h), with Python mirrors of the
+reference's ORBextractor / ORBmatcher interfaces.  No CPU fallback: importing the
+kernels' entry points fails if lib/liborbx.so is missing."""
+from ._lib import KP_DTYPE, MATCH2_DTYPE, QUERY_DTYPE, RECT_DTYPE, OrbxError, lib  # noqa: F401
+from .extractor import ORBextractor, keypoints_from_device  # noqa: F401
+from .matcher import (ORBmatcher, bucket_best, compute_stereo_matches, compute_stereo_matches_device,  # noqa: F401
+                      fisheye_ratio_matches, knn2_merge_device, knn_match2, knn_match2_device, window_candidates)

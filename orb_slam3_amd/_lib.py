@@ -1,0 +1,107 @@
+"""Loader of the HIP library (liborbx.so) and ctypes prototypes of its C ABI.
+
+There is no CPU fallback: if the library is missing or cannot be loaded this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liborbx.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+MATCH2_DTYPE = np.dtype([("idx0", "<i4"), ("dist0", "<i4"), ("idx1", "<i4"), ("dist1", "<i4")])
+QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("xr", "<f4"), ("radius", "<f4"),
+                        ("min_level", "<i4"), ("max_level", "<i4")])
+RECT_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4")])
+
+ORBX_OK, ORBX_ERR_INVALID, ORBX_ERR_CAPACITY, ORBX_ERR_HIP, ORBX_ERR_EMPTY = 0, -1, -2, -3, -4
+
+
+class OrbxParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("max_width", C.c_int),
+                ("max_height", C.c_int), ("max_batch", C.c_int), ("device", C.c_int)]
+
+
+class OrbxError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"orbx status {status}: {msg}")
+        self.status = status
+
+
+# Every symbol include/orbx.h declares, with its prototype.
+PROTOTYPES = {
+    "orbx_last_error": (C.c_char_p, []),
+    "orbx_device_count": (C.c_int, []),
+    "orbx_extractor_create": (C.c_int, [C.POINTER(OrbxParams), C.POINTER(C.c_void_p)]),
+    "orbx_extractor_destroy": (None, [C.c_void_p]),
+    "orbx_extractor_tables": (C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
+    "orbx_extractor_max_keypoints": (C.c_int, [C.c_void_p]),
+    "orbx_extract": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p,
+                               C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "orbx_extract_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "orbx_extract_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t,
+                                            C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_void_p, C.c_void_p]),
+    "orbx_extract_status": (C.c_int, [C.c_void_p]),
+    "orbx_pyramid_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                     C.POINTER(C.c_int)]),
+    "orbx_pyramid_level_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                            C.POINTER(C.c_int), C.POINTER(C.c_ssize_t)]),
+    "orbx_debug_level_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.POINTER(C.c_int)]),
+    "orbx_debug_level_keypoints": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "orbx_descriptor_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "orbx_hamming_knn2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
+    "orbx_knn2_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
+    "orbx_hamming_knn2_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                           C.c_void_p, C.c_size_t, C.c_void_p]),
+    "orbx_knn2_merge_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "orbx_stereo_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "orbx_stereo_match_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orbx_window_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                         C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.POINTER(C.c_int)]),
+    "orbx_search_by_projection": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,
+                                            C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
+                                            C.c_void_p, C.POINTER(C.c_int)]),
+    "orbx_bucket_best": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `make -C orb_slam3_amd/csrc` "
+                              "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)   # raises AttributeError on a missing export
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int):
+    if status != ORBX_OK:
+        raise OrbxError(status, lib().orbx_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,1283 @@
+// ORB extraction on gfx950: pyramid, per-cell FAST with threshold fallback, the fork's
+// per-cell scale round trip, quadtree distribution, orientation, blurred steered-BRIEF
+// descriptors and the lapping-area output order.  Restates ORBextractor::operator()
+// (src/ORBextractor.cc:1271-1399) and everything it calls, batched over frames.
+//
+// Kernel inventory (one launch each per batch, all frames and levels inside the grid,
+// except the pyramid whose levels depend on each other):
+//   k_resize     level l from level l-1       cv::resize INTER_LINEAR   (:1419)
+//   k_fast       one workgroup per FAST cell  cv::FAST + fallback       (:960-970) + round trip (:989-1025)
+//   k_quadtree   one workgroup per level      DistributeOctTree         (:661-883)
+//   k_layout     one workgroup per frame      output order / monoIndex  (:1329-1398)
+//   k_describe   one wave per keypoint        IC_Angle (:90-137), GaussianBlur (:1347),
+//                                             computeOrbDescriptor (:150-213)
+// All integer / float steps are written so that they round exactly like the scalar C++
+// code (no fused multiply-add: this file is compiled with -ffp-contract=off and uses the
+// explicit _rn intrinsics where the order of roundings matters).
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "orbx_common.h"
+#include "orbx_introsort.h"
+
+// ======================================================================================
+// error string
+// ======================================================================================
+static thread_local char g_err[512] = "";
+void orbx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* orbx_last_error(void) { return g_err; }
+extern "C" int orbx_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        orbx_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return ORBX_ERR_HIP;
+    }
+    return n;
+}
+
+// ======================================================================================
+// device tables
+// ======================================================================================
+__constant__ signed char c_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+// umax[v]: half width of row v of the radius-15 disc (ORBextractor.cc:520-535)
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+struct OrbxErr {
+    int cand_overflow;   // a level produced more FAST candidates than candCap
+    int kp_overflow;     // quadtree list / level keypoints exceeded their capacity
+    int out_overflow;    // a frame produced more keypoints than the caller's capacity
+    int need_cand;       // largest candidate count seen (for regrowing)
+};
+
+// ======================================================================================
+// k_resize: 8-bit bilinear resize in 11-bit fixed point, 4 output pixels per lane
+// ======================================================================================
+__global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__ geo, int level,
+                                                uint8_t* __restrict__ pyr, long long frameStride,
+                                                const int* __restrict__ xofs, const short* __restrict__ xcoef,
+                                                const int* __restrict__ yofs, const short* __restrict__ ycoef) {
+    const OrbxLevelGeo& S = geo->lv[level - 1];
+    const OrbxLevelGeo& D = geo->lv[level];
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x4 >= D.w) return;
+    const uint8_t* src = pyr + (long long)blockIdx.z * frameStride + S.off;
+    uint8_t* dst = pyr + (long long)blockIdx.z * frameStride + D.off;
+    const int sy0 = yofs[D.tapY + y];
+    const int sy1 = min(sy0 + 1, S.h - 1);
+    const int b0 = ycoef[2 * (D.tapY + y)], b1 = ycoef[2 * (D.tapY + y) + 1];
+    const uint8_t* r0 = src + (long long)sy0 * S.pitch;
+    const uint8_t* r1 = src + (long long)sy1 * S.pitch;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = min(x4 + i, D.w - 1);
+        const int sx0 = xofs[D.tapX + x];
+        const int sx1 = min(sx0 + 1, S.w - 1);
+        const int a0 = xcoef[2 * (D.tapX + x)], a1 = xcoef[2 * (D.tapX + x) + 1];
+        const int t0 = r0[sx0] * a0 + r0[sx1] * a1;
+        const int t1 = r1[sx0] * a0 + r1[sx1] * a1;
+        const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+        packed |= (uint32_t)(v & 255) << (8 * i);
+    }
+    *reinterpret_cast<uint32_t*>(dst + (long long)y * D.pitch + x4) = packed;   // pitch padding absorbs the tail
+}
+
+// Copies n_frames images (row_stride / frame_stride) into level 0 of each pyramid slab.
+__global__ __launch_bounds__(256) void k_copy_level0(const OrbxFrameGeo* __restrict__ geo,
+                                                     const uint8_t* __restrict__ images, long long rowStride,
+                                                     long long imgStride, uint8_t* __restrict__ pyr,
+                                                     long long frameStride) {
+    const OrbxLevelGeo& D = geo->lv[0];
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x);
+    const int y = blockIdx.y;
+    if (x >= D.w) return;
+    pyr[(long long)blockIdx.z * frameStride + D.off + (long long)y * D.pitch + x] =
+        images[(long long)blockIdx.z * imgStride + (long long)y * rowStride + x];
+}
+
+// ======================================================================================
+// k_fast: FAST-9/16 + 3x3 non-maximum suppression on one ~35-px cell, decided twice
+// (initial threshold, then the lower one if the cell stayed empty), followed by the
+// fork's repeated level<->image scale round trip of every emitted corner.
+// ======================================================================================
+constexpr int kTileP = 80;   // LDS tile pitch; a cell image is at most 75 x 75
+
+__device__ __forceinline__ int fast_strength_lds(const uint8_t* t, int x, int y) {
+    // d[k] = centre - circle[k]; strength = max over the 16 arcs of nine of
+    // max(min(d), -max(d)).  Sliding minima / maxima by doubling: 2, 4, 8, then 9.
+    const int v = t[y * kTileP + x];
+    int d[16];
+    d[0] = v - t[(y + 3) * kTileP + x];
+    d[1] = v - t[(y + 3) * kTileP + x + 1];
+    d[2] = v - t[(y + 2) * kTileP + x + 2];
+    d[3] = v - t[(y + 1) * kTileP + x + 3];
+    d[4] = v - t[y * kTileP + x + 3];
+    d[5] = v - t[(y - 1) * kTileP + x + 3];
+    d[6] = v - t[(y - 2) * kTileP + x + 2];
+    d[7] = v - t[(y - 3) * kTileP + x + 1];
+    d[8] = v - t[(y - 3) * kTileP + x];
+    d[9] = v - t[(y - 3) * kTileP + x - 1];
+    d[10] = v - t[(y - 2) * kTileP + x - 2];
+    d[11] = v - t[(y - 1) * kTileP + x - 3];
+    d[12] = v - t[y * kTileP + x - 3];
+    d[13] = v - t[(y + 1) * kTileP + x - 3];
+    d[14] = v - t[(y + 2) * kTileP + x - 2];
+    d[15] = v - t[(y + 3) * kTileP + x - 1];
+    int mn2[16], mx2[16], mn4[16], mx4[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+    int best = -255;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
+        const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
+        best = max(best, max(mn9, -mx9));
+    }
+    return best;
+}
+
+__device__ __forceinline__ int score_at(int strength, int th) { return strength > th ? strength - 1 : 0; }
+
+// cv::Rect2i::contains(Point2i(pt)): the float point converts with round-half-even.
+__device__ __forceinline__ bool in_any_rect(float X, float Y, const orbx_rect* rects, int nrects) {
+    const int px = __float2int_rn(X), py = __float2int_rn(Y);
+    for (int r = 0; r < nrects; ++r) {
+        const orbx_rect R = rects[r];
+        if (R.x <= px && px < R.x + R.width && R.y <= py && py < R.y + R.height) return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_fast(const OrbxFrameGeo* __restrict__ geo, const uint8_t* __restrict__ pyr,
+                                              long long frameStride, OrbxCand* __restrict__ cands,
+                                              int* __restrict__ candCount, int iniTh, int minTh,
+                                              const orbx_rect* __restrict__ rects, int nrects,
+                                              OrbxErr* __restrict__ err) {
+    __shared__ uint8_t tile[kTileP * kTileP];
+    __shared__ uint8_t strength[kTileP * kTileP];
+    __shared__ int s_nIni, s_nMin;
+    __shared__ uint32_t s_listIni[1296], s_listMin[1296];   // <= ceil(69/2)^2 = 1225 survivors per cell
+
+    const int frame = blockIdx.y;
+    int level = 0;
+    const int nl = geo->nlevels;
+    for (int l = 1; l < nl; ++l)
+        if ((int)blockIdx.x >= geo->lv[l].cellBase) level = l;
+    const OrbxLevelGeo& G = geo->lv[level];
+    const int cell = blockIdx.x - G.cellBase;           // index among processed cells, row-major
+    const int ci = cell / G.nColsP, cj = cell - ci * G.nColsP;
+    const int maxBX = G.w - kOrbxMinBorder, maxBY = G.h - kOrbxMinBorder;
+    const int x0 = kOrbxMinBorder + cj * G.wCell, y0 = kOrbxMinBorder + ci * G.hCell;
+    const int x1 = min(x0 + G.wCell + 6, maxBX), y1 = min(y0 + G.hCell + 6, maxBY);
+    const int tw = x1 - x0, th = y1 - y0;
+    const int tid = threadIdx.x;
+
+    if (tid == 0) { s_nIni = 0; s_nMin = 0; }
+    const uint8_t* img = pyr + (long long)frame * frameStride + G.off;
+    for (int i = tid; i < tw * th; i += 256) {
+        const int y = i / tw, x = i - y * tw;
+        tile[y * kTileP + x] = img[(long long)(y0 + y) * G.pitch + x0 + x];
+        strength[y * kTileP + x] = 0;
+    }
+    __syncthreads();
+
+    const int iw = tw - 6, ih = th - 6;   // pixels FAST can test
+    const int lowTh = min(iniTh, minTh);
+    if (iw > 0 && ih > 0) {
+        for (int i = tid; i < iw * ih; i += 256) {
+            const int y = 3 + i / iw, x = 3 + i % iw;
+            const int s = fast_strength_lds(tile, x, y);
+            strength[y * kTileP + x] = (uint8_t)(s > lowTh ? s : 0);
+        }
+    }
+    __syncthreads();
+    if (iw > 0 && ih > 0) {
+        for (int i = tid; i < iw * ih; i += 256) {
+            const int y = 3 + i / iw, x = 3 + i % iw;
+            const int s = strength[y * kTileP + x];
+            if (s == 0) continue;
+            int nb[8];
+            nb[0] = strength[(y - 1) * kTileP + x - 1]; nb[1] = strength[(y - 1) * kTileP + x];
+            nb[2] = strength[(y - 1) * kTileP + x + 1]; nb[3] = strength[y * kTileP + x - 1];
+            nb[4] = strength[y * kTileP + x + 1];       nb[5] = strength[(y + 1) * kTileP + x - 1];
+            nb[6] = strength[(y + 1) * kTileP + x];     nb[7] = strength[(y + 1) * kTileP + x + 1];
+            const int sI = score_at(s, iniTh), sM = score_at(s, minTh);
+            bool keepI = s > iniTh, keepM = s > minTh;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                keepI = keepI && (sI > score_at(nb[k], iniTh));
+                keepM = keepM && (sM > score_at(nb[k], minTh));
+            }
+            const uint32_t rec = (uint32_t)x | ((uint32_t)y << 7);
+            if (keepI) s_listIni[atomicAdd(&s_nIni, 1)] = rec | ((uint32_t)sI << 14);
+            if (keepM) s_listMin[atomicAdd(&s_nMin, 1)] = rec | ((uint32_t)sM << 14);
+        }
+    }
+    __syncthreads();
+    const bool useIni = s_nIni > 0;
+    const int n = useIni ? s_nIni : s_nMin;
+    const uint32_t* list = useIni ? s_listIni : s_listMin;
+    if (n == 0) return;
+
+    // Round trip: every corner found in the c-th processed cell is scaled to level 0 and
+    // back once for each cell processed from its own to the last one of the level.
+    const int apps = G.nColsP * G.nRowsP - cell;
+    const float s = G.scale, inv = G.invScale;
+    const float border = (float)kOrbxMinBorder;
+    OrbxCand* out = cands + (long long)frame * geo->candTotal + G.candOff;
+    int* counter = candCount + frame * nl + level;
+    for (int i = tid; i < n; i += 256) {
+        const uint32_t rec = list[i];
+        const int lx = rec & 127, ly = (rec >> 7) & 127, sc = rec >> 14;
+        float x = __fadd_rn((float)lx, (float)(cj * G.wCell));
+        float y = __fadd_rn((float)ly, (float)(ci * G.hCell));
+        bool erased = false;
+        for (int a = 0; a < apps; ++a) {
+            const float X = __fmul_rn(__fadd_rn(x, border), s);
+            const float Y = __fmul_rn(__fadd_rn(y, border), s);
+            if (nrects > 0 && in_any_rect(X, Y, rects, nrects)) { erased = true; break; }
+            const float nx = __fsub_rn(__fmul_rn(X, inv), border);
+            const float ny = __fsub_rn(__fmul_rn(Y, inv), border);
+            const bool fixed = (nx == x) && (ny == y);
+            x = nx; y = ny;
+            if (fixed) break;   // further applications reproduce the same values and the same rect test
+        }
+        if (erased) continue;
+        const int pos = atomicAdd(counter, 1);
+        if (pos < G.candCap) {
+            OrbxCand c;
+            c.x = x; c.y = y; c.response = (float)sc;
+            c.order = ((uint32_t)cell << 14) | ((uint32_t)ly << 7) | (uint32_t)lx;
+            out[pos] = c;
+        } else {
+            atomicAdd(&err->cand_overflow, 1);
+            atomicMax(&err->need_cand, pos + 1);
+        }
+    }
+}
+
+// ======================================================================================
+// k_quadtree: DistributeOctTree for one (frame, level) per workgroup.
+//
+// The node list lives in LDS in list order; a split replaces the list by
+//   [children, newest first] ++ [nodes that were not split, old order]
+// exactly as push_front / erase do in the reference.  Keys never move: each carries the
+// index of its node, and only per-node key COUNTS drive the algorithm (a node with one
+// key is final).  The ordering-sensitive parts are reproduced literally: children are
+// created in the order UL, UR, BL, BR; the "expandable" record is in creation order; when
+// the list is about to overshoot N the record is sorted with libstdc++'s introsort and
+// split from the back until the list holds N nodes.  The per-node winner is the key with
+// the highest response, the earliest in emission order among equals.
+// ======================================================================================
+constexpr int kQtThreads = 512;
+
+struct QtBox { short ulx, uly, brx, bry; };
+
+__device__ __forceinline__ int qt_quadrant(const QtBox b, float x, float y) {
+    const int mx = b.ulx + ((b.brx - b.ulx + 1) >> 1);   // UL.x + ceil((UR.x - UL.x) / 2)
+    const int my = b.uly + ((b.bry - b.uly + 1) >> 1);
+    return (x < (float)mx ? 0 : 1) | (y < (float)my ? 0 : 2);
+}
+__device__ __forceinline__ QtBox qt_child_box(const QtBox b, int q) {
+    const short mx = (short)(b.ulx + ((b.brx - b.ulx + 1) >> 1));
+    const short my = (short)(b.uly + ((b.bry - b.uly + 1) >> 1));
+    QtBox c;
+    c.ulx = (q & 1) ? mx : b.ulx;  c.brx = (q & 1) ? b.brx : mx;
+    c.uly = (q & 2) ? my : b.uly;  c.bry = (q & 2) ? b.bry : my;
+    return c;
+}
+
+// Exclusive scan of v[0..n) (in place) by the whole workgroup; returns the total.
+__device__ int qt_block_scan(int* v, int n, int* tmp) {
+    const int tid = threadIdx.x;
+    const int chunk = (n + kQtThreads - 1) / kQtThreads;
+    const int b = tid * chunk, e = min(b + chunk, n);
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += v[i];
+    tmp[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < kQtThreads; off <<= 1) {
+        int add = (tid >= off) ? tmp[tid - off] : 0;
+        __syncthreads();
+        tmp[tid] += add;
+        __syncthreads();
+    }
+    const int total = tmp[kQtThreads - 1];
+    int run = tmp[tid] - sum;
+    for (int i = b; i < e; ++i) { int t = v[i]; v[i] = run; run += t; }
+    __syncthreads();
+    return total;
+}
+
+__global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __restrict__ geo,
+                                                         const OrbxCand* __restrict__ cands,
+                                                         const int* __restrict__ candCount,
+                                                         uint16_t* __restrict__ keyNode,
+                                                         OrbxLevelKp* __restrict__ levelKps,
+                                                         int* __restrict__ kpCount, OrbxErr* __restrict__ err) {
+    extern __shared__ __align__(16) unsigned char qt_smem[];
+    const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const int nl = geo->nlevels;
+    const OrbxLevelGeo& G = geo->lv[level];
+    const int cap = geo->maxNodeCap;
+
+    // LDS carve-up (cap entries each unless noted)
+    unsigned long long* sortbuf = reinterpret_cast<unsigned long long*>(qt_smem);   // expandable record / winners
+    QtBox* boxA = reinterpret_cast<QtBox*>(sortbuf + cap);
+    QtBox* boxB = boxA + cap;
+    int* cntA = reinterpret_cast<int*>(boxB + cap);
+    int* cntB = cntA + cap;
+    int* child = cntB + cap;        // 4 * cap: child key counts, then new indices
+    int* scanv = child + 4 * cap;   // cap: scan input / output
+    int* base = scanv + cap;        // cap: creation sequence base of a split node's children
+    int* tmp = base + cap;          // kQtThreads
+    __shared__ int s_size, s_done, s_nExp, s_total, s_careful, s_nE, s_bad;
+    __shared__ int s_sortStack[3 * orbx_sort::kStackDepth];
+
+    const int n = min(candCount[frame * nl + level], G.candCap);
+    const OrbxCand* C = cands + (long long)frame * geo->candTotal + G.candOff;
+    uint16_t* KN = keyNode + (long long)frame * geo->candTotal + G.candOff;
+    const int N = G.quota;
+    const int H = G.h - 2 * kOrbxMinBorder;
+    const int nIni = G.nIni;
+    const float hX = G.hX;
+
+    QtBox* box = boxA; QtBox* nbox = boxB;
+    int* cnt = cntA;   int* ncnt = cntB;
+
+    // ---- roots ---------------------------------------------------------------------
+    for (int i = tid; i < nIni; i += kQtThreads) child[i] = 0;
+    if (tid == 0) { s_size = 0; s_done = 0; s_bad = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += kQtThreads) {
+        int r = (int)__fdiv_rn(C[i].x, hX);
+        r = min(max(r, 0), nIni - 1);
+        KN[i] = (uint16_t)r;
+        atomicAdd(&child[r], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int sz = 0;
+        for (int r = 0; r < nIni; ++r) {
+            if (child[r] > 0) {
+                QtBox b;
+                b.ulx = (short)(int)__fmul_rn(hX, (float)r);
+                b.brx = (short)(int)__fmul_rn(hX, (float)(r + 1));
+                b.uly = 0; b.bry = (short)H;
+                box[sz] = b; cnt[sz] = child[r];
+                scanv[r] = sz++;
+            } else scanv[r] = 0;
+        }
+        s_size = sz;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kQtThreads) KN[i] = (uint16_t)scanv[KN[i]];
+    __syncthreads();
+
+    // ---- split loop ------------------------------------------------------------------
+    int careful = 0;   // uniform across the workgroup
+    while (true) {
+        const int size = s_size;
+        if (s_done) break;
+        // (1) per-child key counts of every node that can still be split
+        for (int i = tid; i < 4 * size; i += kQtThreads) child[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += kQtThreads) {
+            const int nd = KN[i];
+            if (cnt[nd] > 1) atomicAdd(&child[4 * nd + qt_quadrant(box[nd], C[i].x, C[i].y)], 1);
+        }
+        __syncthreads();
+
+        // (2) choose the nodes to split and the creation order of their children
+        int total;   // number of children created
+        if (!careful) {
+            // full sweep: every node with more than one key, in list order
+            for (int p = tid; p < size; p += kQtThreads) {
+                int nc = 0;
+                if (cnt[p] > 1)
+                    nc = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0);
+                scanv[p] = nc;
+            }
+            __syncthreads();
+            total = qt_block_scan(scanv, size, tmp);
+            for (int p = tid; p < size; p += kQtThreads) base[p] = (cnt[p] > 1) ? scanv[p] : -1;
+            __syncthreads();
+        } else {
+            // careful pass: sort the expandable record, split from the back until N nodes
+            for (int p = tid; p < size; p += kQtThreads) base[p] = -1;
+            __syncthreads();
+            if (tid == 0) {
+                const int nE = s_nE;
+                orbx_sort::sort(sortbuf, nE, s_sortStack);
+                int sz = size, seq = 0;
+                for (int j = nE - 1; j >= 0; --j) {
+                    const int p = (int)orbx_sort::payload_of(sortbuf[j]);
+                    const int nc = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0);
+                    base[p] = seq;
+                    seq += nc;
+                    sz += nc - 1;
+                    if (sz >= N) break;
+                }
+                s_total = seq;
+            }
+            __syncthreads();
+            total = s_total;
+        }
+
+        // (3) positions of the nodes that stay: after all children, old relative order
+        for (int p = tid; p < size; p += kQtThreads) scanv[p] = (base[p] < 0) ? 1 : 0;
+        __syncthreads();
+        const int kept = qt_block_scan(scanv, size, tmp);
+        const int newSize = total + kept;
+        if (newSize > cap) {   // cannot happen for a consistent geometry; never write out of bounds
+            if (tid == 0) { atomicAdd(&err->kp_overflow, 1); s_bad = 1; s_done = 1; }
+            __syncthreads();
+            break;
+        }
+        if (tid == 0) s_nExp = 0;
+        __syncthreads();
+
+        // (4) write the new generation
+        for (int p = tid; p < size; p += kQtThreads) {
+            if (base[p] < 0) {
+                const int np = total + scanv[p];
+                nbox[np] = box[p]; ncnt[np] = cnt[p];
+                child[4 * p] = np;
+            } else {
+                int seq = base[p], nexp = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = child[4 * p + q];
+                    if (c > 0) {
+                        const int np = total - 1 - seq;
+                        ++seq;
+                        nbox[np] = qt_child_box(box[p], q); ncnt[np] = c;
+                        child[4 * p + q] = np;
+                        nexp += (c > 1);
+                    }
+                }
+                if (nexp) atomicAdd(&s_nExp, nexp);
+            }
+        }
+        __syncthreads();
+        // (5) move the keys
+        for (int i = tid; i < n; i += kQtThreads) {
+            const int nd = KN[i];
+            if (base[nd] < 0) KN[i] = (uint16_t)child[4 * nd];
+            else KN[i] = (uint16_t)child[4 * nd + qt_quadrant(box[nd], C[i].x, C[i].y)];
+        }
+        __syncthreads();
+        { QtBox* t = box; box = nbox; nbox = t; int* u = cnt; cnt = ncnt; ncnt = u; }
+
+        // (6) termination / mode switch (ORBextractor.cc:790-858)
+        if (tid == 0) {
+            const int nExp = s_nExp;
+            bool done = (newSize >= N) || (newSize == size);
+            bool toCareful = careful != 0;
+            if (!done && !careful && newSize + 3 * nExp > N) toCareful = true;
+            if (!done && toCareful) {
+                // expandable record in creation order = new positions total-1 .. 0
+                int nE = 0;
+                for (int np = total - 1; np >= 0; --np)
+                    if (cnt[np] > 1)
+                        sortbuf[nE++] = orbx_sort::make_elem((uint32_t)cnt[np], (uint32_t)box[np].ulx, (uint32_t)np);
+                s_nE = nE;
+            }
+            s_careful = toCareful ? 1 : 0;
+            s_done = done ? 1 : 0;
+            s_size = newSize;
+        }
+        __syncthreads();
+        careful = s_careful;
+    }
+    __syncthreads();
+
+    // ---- winners -----------------------------------------------------------------------
+    const int size = s_bad ? 0 : s_size;
+    OrbxLevelKp* out = levelKps + (long long)frame * geo->kpTotal + G.kpOff;
+    if (size > G.kpCap) {
+        if (tid == 0) { atomicAdd(&err->kp_overflow, 1); kpCount[frame * nl + level] = 0; }
+        return;
+    }
+    for (int p = tid; p < size; p += kQtThreads) sortbuf[p] = 0ull;
+    __syncthreads();
+    for (int i = tid; i < n; i += kQtThreads) {
+        const unsigned long long key = ((unsigned long long)(uint32_t)C[i].response << 32) | (uint32_t)(~C[i].order);
+        atomicMax(&sortbuf[KN[i]], key);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kQtThreads) {
+        const OrbxCand c = C[i];
+        const unsigned long long key = ((unsigned long long)(uint32_t)c.response << 32) | (uint32_t)(~c.order);
+        const int nd = KN[i];
+        if (sortbuf[nd] == key) {
+            OrbxLevelKp k;
+            k.x = __fadd_rn(c.x, (float)kOrbxMinBorder);
+            k.y = __fadd_rn(c.y, (float)kOrbxMinBorder);
+            k.response = c.response;
+            k.slot = -1;
+            out[nd] = k;
+        }
+    }
+    if (tid == 0) kpCount[frame * nl + level] = size;
+}
+
+// ======================================================================================
+// k_layout: row of every keypoint in the frame's output (ORBextractor.cc:1329-1398).
+// Keypoints whose level-0 x lies inside [lap0, lap1] fill the arrays from the back,
+// the others from the front, both in (level, list) order.
+// ======================================================================================
+constexpr int kLayThreads = 256;
+
+__global__ __launch_bounds__(kLayThreads) void k_layout(const OrbxFrameGeo* __restrict__ geo,
+                                                        OrbxLevelKp* __restrict__ levelKps,
+                                                        const int* __restrict__ kpCount, int lap0, int lap1,
+                                                        int capacity, int* __restrict__ counts,
+                                                        OrbxErr* __restrict__ err) {
+    __shared__ int s_wave[kLayThreads / 64];
+    __shared__ int s_running;
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int nl = geo->nlevels;
+    OrbxLevelKp* K = levelKps + (long long)frame * geo->kpTotal;
+    int total = 0;
+    for (int l = 0; l < nl; ++l) total += kpCount[frame * nl + l];
+    if (tid == 0) s_running = 0;
+    __syncthreads();
+    const bool overflow = total > capacity;
+    if (overflow && tid == 0) atomicAdd(&err->out_overflow, 1);
+    for (int l = 0; l < nl; ++l) {
+        const OrbxLevelGeo& G = geo->lv[l];
+        const int cnt = kpCount[frame * nl + l];
+        for (int b = 0; b < cnt; b += kLayThreads) {
+            const int i = b + tid;
+            int mono = 0;
+            if (i < cnt) {
+                float x = K[G.kpOff + i].x;
+                if (l != 0) x = __fmul_rn(x, G.scale);
+                mono = (x >= (float)lap0 && x <= (float)lap1) ? 0 : 1;
+            }
+            // ordered rank of the mono flags inside this chunk
+            const unsigned long long bal = __ballot(mono);
+            const int lane = tid & 63, wv = tid >> 6;
+            const int before = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wave[wv] = __popcll(bal);
+            __syncthreads();
+            int wbase = 0, chunkMono = 0;
+            for (int w = 0; w < kLayThreads / 64; ++w) { if (w < wv) wbase += s_wave[w]; chunkMono += s_wave[w]; }
+            const int running = s_running;          // mono keypoints before this chunk
+            const int seen = b;                      // keypoints of this level before this chunk
+            if (i < cnt && !overflow) {
+                const int monoBefore = running + wbase + before;
+                // keypoints before this one in (level, list) order:
+                int prior = seen + (tid);            // inside the level
+                for (int l2 = 0; l2 < l; ++l2) prior += kpCount[frame * nl + l2];
+                const int stereoBefore = prior - monoBefore;
+                K[G.kpOff + i].slot = mono ? monoBefore : (total - 1 - stereoBefore);
+            }
+            __syncthreads();
+            if (tid == 0) s_running = running + chunkMono;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        counts[2 * frame] = overflow ? 0 : total;
+        counts[2 * frame + 1] = overflow ? 0 : s_running;
+    }
+}
+
+// ======================================================================================
+// k_describe: one wave per kept keypoint.
+//   raw 43x43 patch -> LDS (REFLECT_101 at the level's own edges)
+//   IC_Angle on the raw patch, fastAtan2
+//   7x7 Gaussian (8.8 fixed point, taps 18 34 48 56 48 34 18) on the 37x37 core
+//   256 steered comparisons -> 32 bytes
+// ======================================================================================
+constexpr int kDescWaves = 4;
+constexpr int kRawR = 21, kRawW = 43, kRawP = 44;
+constexpr int kBlurR = 18, kBlurW = 37, kBlurP = 40;
+
+__device__ __forceinline__ int reflect101_dev(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = (p < 0) ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float k = (float)(180 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * k, p3 = -0.3258083974640975f * k;
+    const float p5 = 0.1555786518463281f * k, p7 = -0.04432655554792128f * k;
+    const float eps = (float)2.2204460492503131e-16;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// cos / sin of a binary32 angle in [0, 2 pi], evaluated in binary64 and rounded once.
+__device__ __forceinline__ void sincos_f32(float xf, float* s_out, float* c_out) {
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double pio2_hi = 1.57079632673412561417e+00;
+    const double pio2_lo = 6.07710050650619224932e-11;
+    const double x = (double)xf;
+    const int k = (int)__dadd_rn(__dmul_rn(x, two_over_pi), 0.5);
+    const double r = __dsub_rn(__dsub_rn(x, __dmul_rn((double)k, pio2_hi)), __dmul_rn((double)k, pio2_lo));
+    const double z = __dmul_rn(r, r);
+    double sp = 1.0 / 355687428096000.0;
+    sp = __dsub_rn(__dmul_rn(sp, z), 1.0 / 1307674368000.0);
+    sp = __dadd_rn(__dmul_rn(sp, z), 1.0 / 6227020800.0);
+    sp = __dsub_rn(__dmul_rn(sp, z), 1.0 / 39916800.0);
+    sp = __dadd_rn(__dmul_rn(sp, z), 1.0 / 362880.0);
+    sp = __dsub_rn(__dmul_rn(sp, z), 1.0 / 5040.0);
+    sp = __dadd_rn(__dmul_rn(sp, z), 1.0 / 120.0);
+    sp = __dsub_rn(__dmul_rn(sp, z), 1.0 / 6.0);
+    const double sn = __dadd_rn(r, __dmul_rn(__dmul_rn(r, z), sp));
+    double cp = 1.0 / 20922789888000.0;
+    cp = __dsub_rn(__dmul_rn(cp, z), 1.0 / 87178291200.0);
+    cp = __dadd_rn(__dmul_rn(cp, z), 1.0 / 479001600.0);
+    cp = __dsub_rn(__dmul_rn(cp, z), 1.0 / 3628800.0);
+    cp = __dadd_rn(__dmul_rn(cp, z), 1.0 / 40320.0);
+    cp = __dsub_rn(__dmul_rn(cp, z), 1.0 / 720.0);
+    cp = __dadd_rn(__dmul_rn(cp, z), 1.0 / 24.0);
+    const double cs = __dsub_rn(1.0, __dsub_rn(__dmul_rn(0.5, z), __dmul_rn(__dmul_rn(z, z), cp)));
+    double s, c;
+    switch (k & 3) {
+        case 0: s = sn; c = cs; break;
+        case 1: s = cs; c = -sn; break;
+        case 2: s = -sn; c = -cs; break;
+        default: s = -cs; c = sn; break;
+    }
+    *s_out = (float)s;
+    *c_out = (float)c;
+}
+
+__global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo* __restrict__ geo,
+                                                              const uint8_t* __restrict__ pyr, long long frameStride,
+                                                              const OrbxLevelKp* __restrict__ levelKps,
+                                                              const int* __restrict__ kpCount,
+                                                              orbx_keypoint* __restrict__ outKps,
+                                                              uint8_t* __restrict__ outDesc, int capacity) {
+    __shared__ uint8_t s_raw[kDescWaves][kRawW * kRawP];
+    __shared__ uint16_t s_hor[kDescWaves][kRawW * kBlurP];
+    __shared__ uint8_t s_blur[kDescWaves][kBlurW * kBlurP];
+
+    const int frame = blockIdx.y;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ordinal = blockIdx.x * kDescWaves + wv;
+    const int nl = geo->nlevels;
+    int level = -1, idx = 0;
+    for (int l = 0; l < nl; ++l) {
+        const int o = ordinal - geo->lv[l].kpOff;
+        if (o >= 0 && o < geo->lv[l].kpCap) { level = l; idx = o; }
+    }
+    // Waves without a keypoint stay in step (they only skip the work) so that every
+    // wave of the workgroup reaches the barriers below.
+    bool active = level >= 0;
+    if (active) active = idx < kpCount[frame * nl + level];
+    const OrbxLevelGeo& G = geo->lv[active ? level : 0];
+    OrbxLevelKp kp;
+    kp.x = 0.f; kp.y = 0.f; kp.response = 0.f; kp.slot = -1;
+    if (active) kp = levelKps[(long long)frame * geo->kpTotal + G.kpOff + idx];
+    active = active && kp.slot >= 0 && kp.slot < capacity;
+    const uint8_t* img = pyr + (long long)frame * frameStride + G.off;
+    const int cx = __float2int_rn(kp.x), cy = __float2int_rn(kp.y);
+
+    uint8_t* raw = s_raw[wv];
+    uint16_t* hor = s_hor[wv];
+    uint8_t* blur = s_blur[wv];
+
+    if (active) {
+        for (int i = lane; i < kRawW * kRawW; i += 64) {
+            const int r = i / kRawW, c = i - r * kRawW;
+            const int yy = reflect101_dev(cy - kRawR + r, G.h), xx = reflect101_dev(cx - kRawR + c, G.w);
+            raw[r * kRawP + c] = img[(long long)yy * G.pitch + xx];
+        }
+    }
+    __syncthreads();
+
+    // ---- orientation: m10 = sum u*I, m01 = sum v*I over the radius-15 disc ----
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < 31 * 31; i += 64) {
+        const int v = i / 31 - 15, u = i % 31 - 15;
+        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
+        if (au <= c_umax[av]) {
+            const int p = raw[(kRawR + v) * kRawP + kRawR + u];
+            m10 += u * p;
+            m01 += v * p;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        m10 += __shfl_xor(m10, off);
+        m01 += __shfl_xor(m01, off);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // ---- separable 7-tap blur of the 37x37 core ----
+    for (int i = lane; active && i < kRawW * kBlurW; i += 64) {
+        const int r = i / kBlurW, c = i - r * kBlurW;   // output column c <-> raw columns c .. c+6
+        const uint8_t* p = raw + r * kRawP + c;
+        hor[r * kBlurP + c] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
+    }
+    __syncthreads();
+    for (int i = lane; active && i < kBlurW * kBlurW; i += 64) {
+        const int r = i / kBlurW, c = i - r * kBlurW;
+        const uint16_t* p = hor + r * kBlurP + c;
+        const uint32_t s = 18u * (p[0] + p[6 * kBlurP]) + 34u * (p[kBlurP] + p[5 * kBlurP]) +
+                           48u * (p[2 * kBlurP] + p[4 * kBlurP]) + 56u * p[3 * kBlurP];
+        blur[r * kBlurP + c] = (uint8_t)((s + 32768u) >> 16);
+    }
+    __syncthreads();
+
+    if (!active) return;
+    // ---- steered BRIEF: lane handles comparisons 4*lane .. 4*lane+3 ----
+    const float deg2rad = (float)(3.14159265358979323846 / 180.f);
+    float a, b;
+    sincos_f32(__fmul_rn(angle, deg2rad), &b, &a);
+    uint32_t nib = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int t[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int pi = ((lane * 4 + j) * 2 + e) * 2;
+            const float px = (float)c_pattern[pi], py = (float)c_pattern[pi + 1];
+            const int ry = __float2int_rn(__fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a)));
+            const int rx = __float2int_rn(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b)));
+            t[e] = blur[(kBlurR + ry) * kBlurP + kBlurR + rx];
+        }
+        nib |= (uint32_t)(t[0] < t[1]) << j;
+    }
+    const uint32_t other = __shfl_xor(nib, 1);
+    const long long row = (long long)frame * capacity + kp.slot;
+    if ((lane & 1) == 0) outDesc[row * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
+    if (lane == 0) {
+        orbx_keypoint k;
+        k.x = kp.x; k.y = kp.y;
+        if (level != 0) { k.x = __fmul_rn(kp.x, G.scale); k.y = __fmul_rn(kp.y, G.scale); }
+        k.size = G.patchSize;
+        k.angle = angle;
+        k.response = kp.response;
+        k.octave = level;
+        k.class_id = -1;
+        outKps[row] = k;
+    }
+}
+
+// ======================================================================================
+// host side
+// ======================================================================================
+static inline int round_half_even_f(float v) { return (int)std::nearbyintf(v); }
+
+struct orbx_extractor {
+    orbx_params prm;
+    int device = 0;
+    std::vector<float> sf, inv_sf, sigma2, inv_sigma2;
+    std::vector<int> quota;
+    OrbxFrameGeo geo;
+    bool geoValid = false;
+    int candShift = 3;            // candCap = level pixels >> candShift
+
+    hipStream_t stream = nullptr;
+    OrbxFrameGeo* d_geo = nullptr;
+    uint8_t* d_pyr = nullptr;      size_t pyrAlloc = 0;
+    OrbxCand* d_cands = nullptr;   size_t candAlloc = 0;
+    uint16_t* d_keyNode = nullptr;
+    OrbxLevelKp* d_levelKps = nullptr; size_t kpAlloc = 0;
+    int* d_candCount = nullptr;    // max_batch * nlevels
+    int* d_kpCount = nullptr;      // max_batch * nlevels
+    OrbxErr* d_err = nullptr;
+    OrbxErr* h_err = nullptr;      // pinned
+    orbx_rect* d_rects = nullptr;
+    int *d_xofs = nullptr, *d_yofs = nullptr;
+    short *d_xcoef = nullptr, *d_ycoef = nullptr;
+    size_t tapAlloc = 0;
+    // staging for the host entry points
+    orbx_keypoint* d_outKps = nullptr;
+    uint8_t* d_outDesc = nullptr;
+    int* d_counts = nullptr;
+    int outCap = 0;
+    int lastFrames = 0;
+    void* d_scratch = nullptr;     size_t scratchAlloc = 0;
+};
+
+static void host_linear_taps(int ssize, int dsize, int* ofs, short* coef) {
+    // cv::resize's coefficient set-up for INTER_LINEAR, 8-bit: 11-bit fixed point
+    const double inv_scale = (double)dsize / ssize;
+    const double scale = 1. / inv_scale;
+    for (int d = 0; d < dsize; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= s;
+        if (s < 0) { f = 0; s = 0; }
+        if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        ofs[d] = s;
+        coef[2 * d] = (short)round_half_even_f((1.f - f) * 2048.f);
+        coef[2 * d + 1] = (short)round_half_even_f(f * 2048.f);
+    }
+}
+
+static void free_geo_buffers(orbx_extractor* ex) {
+    hipFree(ex->d_pyr); ex->d_pyr = nullptr;
+    hipFree(ex->d_cands); ex->d_cands = nullptr;
+    hipFree(ex->d_keyNode); ex->d_keyNode = nullptr;
+    hipFree(ex->d_levelKps); ex->d_levelKps = nullptr;
+    hipFree(ex->d_xofs); ex->d_xofs = nullptr;
+    hipFree(ex->d_yofs); ex->d_yofs = nullptr;
+    hipFree(ex->d_xcoef); ex->d_xcoef = nullptr;
+    hipFree(ex->d_ycoef); ex->d_ycoef = nullptr;
+}
+
+// Computes the level / cell / quadtree geometry for a w x h image and (re)allocates the
+// device slabs.  Called at creation for the maximum size and again when the size changes.
+static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
+    const orbx_params& P = ex->prm;
+    OrbxFrameGeo& g = ex->geo;
+    memset(&g, 0, sizeof(g));
+    g.nlevels = P.nlevels; g.w = w; g.h = h;
+    long long off = 0, candOff = 0;
+    int kpOff = 0, cellBase = 0, tapX = 0, tapY = 0, maxNode = 0;
+    for (int l = 0; l < P.nlevels; ++l) {
+        OrbxLevelGeo& L = g.lv[l];
+        L.w = round_half_even_f((float)w * ex->inv_sf[l]);
+        L.h = round_half_even_f((float)h * ex->inv_sf[l]);
+        const float width = (float)(L.w - 2 * kOrbxMinBorder), height = (float)(L.h - 2 * kOrbxMinBorder);
+        ORBX_REQUIRE(width >= 35.f && height >= 35.f,
+                     "level %d of a %dx%d image is %dx%d: too small for the 35-px FAST grid", l, w, h, L.w, L.h);
+        ORBX_REQUIRE(L.w < 32000 && L.h < 32000, "image too large");
+        L.pitch = (L.w + 63) & ~63;
+        L.off = off;
+        off += (long long)L.pitch * L.h;
+        off = (off + 255) & ~255ll;
+        L.nCols = (int)(width / 35.f); L.nRows = (int)(height / 35.f);
+        L.wCell = (int)std::ceil(width / L.nCols); L.hCell = (int)std::ceil(height / L.nRows);
+        const int maxBX = L.w - kOrbxMinBorder, maxBY = L.h - kOrbxMinBorder;
+        L.nColsP = 0; L.nRowsP = 0;
+        for (int j = 0; j < L.nCols; ++j) if (!((float)(kOrbxMinBorder + j * L.wCell) >= (float)(maxBX - 3))) L.nColsP = j + 1;
+        for (int i = 0; i < L.nRows; ++i) if (!((float)(kOrbxMinBorder + i * L.hCell) >= (float)(maxBY - 3))) L.nRowsP = i + 1;
+        ORBX_REQUIRE(L.wCell + 6 <= 75 && L.hCell + 6 <= 75, "FAST cell of level %d is %dx%d: unsupported", l, L.wCell, L.hCell);
+        L.cellBase = cellBase;
+        cellBase += L.nColsP * L.nRowsP;
+        L.quota = ex->quota[l];
+        L.nIni = (int)std::round((float)(maxBX - kOrbxMinBorder) / (maxBY - kOrbxMinBorder));
+        ORBX_REQUIRE(L.nIni >= 1, "level %d is taller than twice its width: the quadtree has no root", l);
+        L.hX = (float)(maxBX - kOrbxMinBorder) / L.nIni;
+        long long px = (long long)L.w * L.h;
+        L.candCap = (int)std::min<long long>(std::max<long long>(px >> ex->candShift, 2048), (px + 3) / 4 + 16);
+        L.candOff = candOff;
+        candOff += L.candCap;
+        L.nodeCap = std::max(L.quota, 4 * L.nIni) + 8;
+        L.kpCap = L.nodeCap;
+        L.kpOff = kpOff;
+        kpOff += L.kpCap;
+        maxNode = std::max(maxNode, L.nodeCap);
+        L.scale = ex->sf[l];
+        L.invScale = 1 / L.scale;
+        L.patchSize = (float)(int)(31 * ex->sf[l]);
+        L.tapX = tapX; L.tapY = tapY;
+        tapX += L.w; tapY += L.h;
+    }
+    ORBX_REQUIRE(maxNode <= 2800, "nfeatures too large for the on-chip quadtree (%d nodes per level, limit 2800)", maxNode);
+    g.totalCells = cellBase;
+    g.pyrBytes = off;
+    g.candTotal = candOff;
+    g.kpTotal = kpOff;
+    g.maxNodeCap = maxNode;
+
+    {
+        const size_t qtLds = (size_t)maxNode * 56 + kQtThreads * sizeof(int);
+        int ldsMax = 0;
+        ORBX_HIP_TRY(hipDeviceGetAttribute(&ldsMax, hipDeviceAttributeMaxSharedMemoryPerBlock, ex->device));
+        ORBX_REQUIRE((long long)qtLds + 2048 <= ldsMax, "quadtree needs %zu bytes of LDS, the device offers %d", qtLds, ldsMax);
+        if (qtLds > 32 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)qtLds);
+            if (e != hipSuccess) {
+                orbx_set_error("cannot raise the dynamic LDS limit of the quadtree kernel to %zu (device max %d): %s", qtLds,
+                               ldsMax, hipGetErrorString(e));
+                return ORBX_ERR_HIP;
+            }
+        }
+    }
+    free_geo_buffers(ex);
+    const size_t B = (size_t)P.max_batch;
+    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_pyr, B * (size_t)g.pyrBytes + 256));
+    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_cands, B * (size_t)g.candTotal * sizeof(OrbxCand)));
+    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_keyNode, B * (size_t)g.candTotal * sizeof(uint16_t)));
+    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_levelKps, B * (size_t)g.kpTotal * sizeof(OrbxLevelKp)));
+    std::vector<int> xo(tapX), yo(tapY);
+    std::vector<short> xc(2 * (size_t)tapX), yc(2 * (size_t)tapY);
+    for (int l = 1; l < P.nlevels; ++l) {
+        host_linear_taps(g.lv[l - 1].w, g.lv[l].w, &xo[g.lv[l].tapX], &xc[2 * (size_t)g.lv[l].tapX]);
+        host_linear_taps(g.lv[l - 1].h, g.lv[l].h, &yo[g.lv[l].tapY], &yc[2 * (size_t)g.lv[l].tapY]);
+    }
+    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_xofs, tapX * sizeof(int)));
+    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_yofs, tapY * sizeof(int)));
+    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_xcoef, 2 * (size_t)tapX * sizeof(short)));
+    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_ycoef, 2 * (size_t)tapY * sizeof(short)));
+    ORBX_HIP_TRY(hipMemcpy(ex->d_xofs, xo.data(), tapX * sizeof(int), hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(ex->d_yofs, yo.data(), tapY * sizeof(int), hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(ex->d_xcoef, xc.data(), 2 * (size_t)tapX * sizeof(short), hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(ex->d_ycoef, yc.data(), 2 * (size_t)tapY * sizeof(short), hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(ex->d_geo, &g, sizeof(g), hipMemcpyHostToDevice));
+    ex->geoValid = true;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_extractor_create(const orbx_params* p, orbx_extractor** out) {
+    ORBX_REQUIRE(p && out, "null argument");
+    ORBX_REQUIRE(p->nlevels >= 1 && p->nlevels <= kOrbxMaxLevels, "nlevels must be in [1, %d]", kOrbxMaxLevels);
+    ORBX_REQUIRE(p->nfeatures >= 1, "nfeatures must be positive");
+    ORBX_REQUIRE(p->scale_factor > 1.0f, "scale_factor must be > 1");
+    ORBX_REQUIRE(p->max_width > 0 && p->max_height > 0 && p->max_batch >= 1, "bad size / batch");
+    int ndev = 0;
+    ORBX_HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { orbx_set_error("no HIP device"); return ORBX_ERR_HIP; }
+    orbx_extractor* ex = new orbx_extractor;
+    ex->prm = *p;
+    if (p->device >= 0) ORBX_HIP_TRY(hipSetDevice(p->device));
+    ORBX_HIP_TRY(hipGetDevice(&ex->device));
+    const int nl = p->nlevels;
+    // scale tables and per-level quotas: ORBextractor.cc:481-512 (scaleFactor is a double member)
+    const double scaleFactor = (double)p->scale_factor;
+    ex->sf.resize(nl); ex->inv_sf.resize(nl); ex->sigma2.resize(nl); ex->inv_sigma2.resize(nl); ex->quota.resize(nl);
+    ex->sf[0] = 1.f; ex->sigma2[0] = 1.f;
+    for (int i = 1; i < nl; ++i) { ex->sf[i] = (float)(ex->sf[i - 1] * scaleFactor); ex->sigma2[i] = ex->sf[i] * ex->sf[i]; }
+    for (int i = 0; i < nl; ++i) { ex->inv_sf[i] = 1.0f / ex->sf[i]; ex->inv_sigma2[i] = 1.0f / ex->sigma2[i]; }
+    const float factor = (float)(1.0f / scaleFactor);
+    float per = p->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; ++l) { ex->quota[l] = round_half_even_f(per); sum += ex->quota[l]; per *= factor; }
+    ex->quota[nl - 1] = std::max(p->nfeatures - sum, 0);
+
+    orbx_status st = ORBX_OK;
+    auto fail = [&](orbx_status s) { orbx_extractor_destroy(ex); return s; };
+    if (hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking) != hipSuccess) { orbx_set_error("hipStreamCreate failed"); return fail(ORBX_ERR_HIP); }
+    const size_t B = (size_t)p->max_batch;
+    if (hipMalloc((void**)&ex->d_geo, sizeof(OrbxFrameGeo)) != hipSuccess ||
+        hipMalloc((void**)&ex->d_candCount, B * nl * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&ex->d_kpCount, B * nl * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&ex->d_err, sizeof(OrbxErr)) != hipSuccess ||
+        hipMalloc((void**)&ex->d_rects, kOrbxMaxRects * sizeof(orbx_rect)) != hipSuccess ||
+        hipHostMalloc((void**)&ex->h_err, sizeof(OrbxErr)) != hipSuccess) {
+        orbx_set_error("device allocation failed");
+        return fail(ORBX_ERR_HIP);
+    }
+    memset(ex->h_err, 0, sizeof(OrbxErr));
+    st = setup_geometry(ex, p->max_width, p->max_height);
+    if (st != ORBX_OK) return fail(st);
+    ex->outCap = orbx_extractor_max_keypoints(ex);
+    if (hipMalloc((void**)&ex->d_outKps, B * ex->outCap * sizeof(orbx_keypoint)) != hipSuccess ||
+        hipMalloc((void**)&ex->d_outDesc, B * ex->outCap * 32) != hipSuccess ||
+        hipMalloc((void**)&ex->d_counts, B * 2 * sizeof(int)) != hipSuccess) {
+        orbx_set_error("device allocation failed");
+        return fail(ORBX_ERR_HIP);
+    }
+    *out = ex;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_extractor_destroy(orbx_extractor* ex) {
+    if (!ex) return;
+    hipSetDevice(ex->device);
+    if (ex->stream) { hipStreamSynchronize(ex->stream); hipStreamDestroy(ex->stream); }
+    free_geo_buffers(ex);
+    hipFree(ex->d_geo); hipFree(ex->d_candCount); hipFree(ex->d_kpCount); hipFree(ex->d_err);
+    hipFree(ex->d_rects); hipFree(ex->d_scratch); hipFree(ex->d_outKps); hipFree(ex->d_outDesc); hipFree(ex->d_counts);
+    if (ex->h_err) hipHostFree(ex->h_err);
+    delete ex;
+}
+
+extern "C" orbx_status orbx_extractor_tables(const orbx_extractor* ex, float* scale, float* inv_scale, float* sigma2,
+                                             float* inv_sigma2, int* features_per_level) {
+    ORBX_REQUIRE(ex, "null handle");
+    for (int i = 0; i < ex->prm.nlevels; ++i) {
+        if (scale) scale[i] = ex->sf[i];
+        if (inv_scale) inv_scale[i] = ex->inv_sf[i];
+        if (sigma2) sigma2[i] = ex->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = ex->inv_sigma2[i];
+        if (features_per_level) features_per_level[i] = ex->quota[i];
+    }
+    return ORBX_OK;
+}
+
+extern "C" int orbx_extractor_max_keypoints(const orbx_extractor* ex) {
+    if (!ex) return 0;
+    return ex->geo.kpTotal;
+}
+
+static orbx_status ensure_geometry(orbx_extractor* ex, int w, int h) {
+    ORBX_REQUIRE(w <= ex->prm.max_width && h <= ex->prm.max_height, "image %dx%d exceeds the handle's %dx%d", w, h,
+                 ex->prm.max_width, ex->prm.max_height);
+    if (ex->geoValid && ex->geo.w == w && ex->geo.h == h) return ORBX_OK;
+    ORBX_HIP_TRY(hipStreamSynchronize(ex->stream));
+    return setup_geometry(ex, w, h);
+}
+
+// Enqueues every kernel of one batch.  Level 0 of each pyramid slab must already hold the image.
+static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1, const orbx_rect* dyn, int ndyn,
+                                 orbx_keypoint* d_kps, uint8_t* d_desc, int capacity, int* d_counts, hipStream_t st) {
+    const OrbxFrameGeo& g = ex->geo;
+    const int nl = g.nlevels;
+    ORBX_REQUIRE(ndyn >= 0 && ndyn <= kOrbxMaxRects, "at most %d dynamic rectangles", kOrbxMaxRects);
+    if (ndyn > 0) ORBX_HIP_TRY(hipMemcpyAsync(ex->d_rects, dyn, ndyn * sizeof(orbx_rect), hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(hipMemsetAsync(ex->d_candCount, 0, (size_t)nf * nl * sizeof(int), st));
+    ORBX_HIP_TRY(hipMemsetAsync(ex->d_kpCount, 0, (size_t)nf * nl * sizeof(int), st));
+    ORBX_HIP_TRY(hipMemsetAsync(ex->d_err, 0, sizeof(OrbxErr), st));
+    for (int l = 1; l < nl; ++l) {
+        dim3 grid((g.lv[l].w + 4 * 256 - 1) / (4 * 256), g.lv[l].h, nf);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, ex->d_geo, l, ex->d_pyr, g.pyrBytes, ex->d_xofs, ex->d_xcoef,
+                           ex->d_yofs, ex->d_ycoef);
+    }
+    hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nf), dim3(256), 0, st, ex->d_geo, ex->d_pyr, g.pyrBytes, ex->d_cands,
+                       ex->d_candCount, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->d_rects, ndyn, ex->d_err);
+    const size_t qtLds = (size_t)g.maxNodeCap * 56 + kQtThreads * sizeof(int);
+    hipLaunchKernelGGL(k_quadtree, dim3(nl, nf), dim3(kQtThreads), qtLds, st, ex->d_geo, ex->d_cands, ex->d_candCount,
+                       ex->d_keyNode, ex->d_levelKps, ex->d_kpCount, ex->d_err);
+    hipLaunchKernelGGL(k_layout, dim3(nf), dim3(kLayThreads), 0, st, ex->d_geo, ex->d_levelKps, ex->d_kpCount, lap0, lap1,
+                       capacity, d_counts, ex->d_err);
+    hipLaunchKernelGGL(k_describe, dim3((g.kpTotal + kDescWaves - 1) / kDescWaves, nf), dim3(64 * kDescWaves), 0, st,
+                       ex->d_geo, ex->d_pyr, g.pyrBytes, ex->d_levelKps, ex->d_kpCount, d_kps, d_desc, capacity);
+    ORBX_HIP_TRY(hipMemcpyAsync(ex->h_err, ex->d_err, sizeof(OrbxErr), hipMemcpyDeviceToHost, st));
+    ORBX_HIP_TRY(hipGetLastError());
+    ex->lastFrames = nf;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, int n_frames, int width,
+                                                 int height, ptrdiff_t row_stride, ptrdiff_t frame_stride, int lap0,
+                                                 int lap1, const orbx_rect* dyn_host, int ndyn, orbx_keypoint* d_keypoints,
+                                                 uint8_t* d_descriptors, int capacity, int* d_counts, void* stream) {
+    ORBX_REQUIRE(ex && d_images && d_keypoints && d_descriptors && d_counts, "null argument");
+    ORBX_REQUIRE(n_frames >= 1 && n_frames <= ex->prm.max_batch, "n_frames %d outside [1, %d]", n_frames, ex->prm.max_batch);
+    ORBX_REQUIRE(width > 0 && height > 0 && row_stride >= width, "bad image size / stride");
+    ORBX_HIP_TRY(hipSetDevice(ex->device));
+    orbx_status s = ensure_geometry(ex, width, height);
+    if (s != ORBX_OK) return s;
+    hipStream_t st = stream ? (hipStream_t)stream : ex->stream;
+    dim3 grid((width + 255) / 256, height, n_frames);
+    hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, st, ex->d_geo, d_images, (long long)row_stride,
+                       (long long)frame_stride, ex->d_pyr, ex->geo.pyrBytes);
+    return enqueue_batch(ex, n_frames, lap0, lap1, dyn_host, ndyn, d_keypoints, d_descriptors, capacity, d_counts, st);
+}
+
+extern "C" orbx_status orbx_extract_status(orbx_extractor* ex) {
+    ORBX_REQUIRE(ex, "null handle");
+    const OrbxErr e = *ex->h_err;
+    if (e.cand_overflow) {
+        // regrow so that the next call fits
+        while (ex->candShift > 0) {
+            --ex->candShift;
+            bool ok = true;
+            for (int l = 0; l < ex->geo.nlevels; ++l)
+                if (((long long)ex->geo.lv[l].w * ex->geo.lv[l].h >> ex->candShift) < e.need_cand) ok = false;
+            if (ok) break;
+        }
+        const int w = ex->geo.w, h = ex->geo.h;
+        hipStreamSynchronize(ex->stream);
+        orbx_status s = setup_geometry(ex, w, h);
+        if (s != ORBX_OK) return s;
+        orbx_set_error("FAST candidate buffer overflowed (%d needed); buffers regrown, call again", e.need_cand);
+        return ORBX_ERR_CAPACITY;
+    }
+    if (e.kp_overflow) { orbx_set_error("quadtree node capacity exceeded"); return ORBX_ERR_CAPACITY; }
+    if (e.out_overflow) { orbx_set_error("output capacity too small for the keypoints of a frame"); return ORBX_ERR_CAPACITY; }
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_extract_batch(orbx_extractor* ex, const uint8_t* const* images, int n_frames, int width,
+                                          int height, ptrdiff_t stride, int lap0, int lap1, orbx_keypoint* keypoints,
+                                          uint8_t* descriptors, int capacity, int* n_out, int* mono_index_out) {
+    ORBX_REQUIRE(ex && images && n_out && mono_index_out, "null argument");
+    ORBX_REQUIRE(n_frames >= 1 && n_frames <= ex->prm.max_batch, "n_frames %d outside [1, %d]", n_frames, ex->prm.max_batch);
+    if (width <= 0 || height <= 0) { orbx_set_error("empty image"); return ORBX_ERR_EMPTY; }
+    ORBX_REQUIRE(stride >= width, "stride smaller than width");
+    ORBX_HIP_TRY(hipSetDevice(ex->device));
+    orbx_status s = ensure_geometry(ex, width, height);
+    if (s != ORBX_OK) return s;
+    const OrbxLevelGeo& L0 = ex->geo.lv[0];
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        for (int f = 0; f < n_frames; ++f) {
+            if (!images[f]) { orbx_set_error("empty image"); return ORBX_ERR_EMPTY; }
+            ORBX_HIP_TRY(hipMemcpy2DAsync(ex->d_pyr + (size_t)f * ex->geo.pyrBytes + L0.off, L0.pitch, images[f], stride,
+                                          width, height, hipMemcpyHostToDevice, ex->stream));
+        }
+        s = enqueue_batch(ex, n_frames, lap0, lap1, nullptr, 0, ex->d_outKps, ex->d_outDesc, ex->outCap, ex->d_counts,
+                          ex->stream);
+        if (s != ORBX_OK) return s;
+        ORBX_HIP_TRY(hipStreamSynchronize(ex->stream));
+        s = orbx_extract_status(ex);
+        if (s == ORBX_ERR_CAPACITY && ex->h_err->cand_overflow) continue;   // regrown: run again
+        if (s != ORBX_OK) return s;
+        break;
+    }
+    if (s != ORBX_OK) return s;
+    std::vector<int> counts(2 * (size_t)n_frames);
+    ORBX_HIP_TRY(hipMemcpy(counts.data(), ex->d_counts, counts.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int f = 0; f < n_frames; ++f) {
+        const int n = counts[2 * f];
+        n_out[f] = n;
+        mono_index_out[f] = counts[2 * f + 1];
+        if (n > capacity) { orbx_set_error("frame %d has %d keypoints, capacity is %d", f, n, capacity); return ORBX_ERR_CAPACITY; }
+        if (n > 0) {
+            ORBX_REQUIRE(keypoints && descriptors, "null output buffer");
+            ORBX_HIP_TRY(hipMemcpy(keypoints + (size_t)f * capacity, ex->d_outKps + (size_t)f * ex->outCap,
+                                   n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+            ORBX_HIP_TRY(hipMemcpy(descriptors + (size_t)f * capacity * 32, ex->d_outDesc + (size_t)f * ex->outCap * 32,
+                                   (size_t)n * 32, hipMemcpyDeviceToHost));
+        }
+    }
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_extract(orbx_extractor* ex, const uint8_t* image, int width, int height, ptrdiff_t stride,
+                                    int lap0, int lap1, const orbx_rect* dyn, int ndyn, orbx_keypoint* keypoints,
+                                    uint8_t* descriptors, int capacity, int* n_out, int* mono_index_out) {
+    ORBX_REQUIRE(ex && n_out && mono_index_out, "null argument");
+    if (!image || width <= 0 || height <= 0) {
+        orbx_set_error("empty image");
+        *n_out = 0; *mono_index_out = -1;
+        return ORBX_ERR_EMPTY;
+    }
+    if (ndyn == 0) return orbx_extract_batch(ex, &image, 1, width, height, stride, lap0, lap1, keypoints, descriptors,
+                                             capacity, n_out, mono_index_out);
+    // with dynamic rectangles: same path, rectangles uploaded per call
+    ORBX_REQUIRE(stride >= width, "stride smaller than width");
+    ORBX_REQUIRE(dyn && ndyn > 0 && ndyn <= kOrbxMaxRects, "bad rectangle list");
+    ORBX_HIP_TRY(hipSetDevice(ex->device));
+    orbx_status s = ensure_geometry(ex, width, height);
+    if (s != ORBX_OK) return s;
+    const OrbxLevelGeo& L0 = ex->geo.lv[0];
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        ORBX_HIP_TRY(hipMemcpy2DAsync(ex->d_pyr + L0.off, L0.pitch, image, stride, width, height, hipMemcpyHostToDevice,
+                                      ex->stream));
+        s = enqueue_batch(ex, 1, lap0, lap1, dyn, ndyn, ex->d_outKps, ex->d_outDesc, ex->outCap, ex->d_counts, ex->stream);
+        if (s != ORBX_OK) return s;
+        ORBX_HIP_TRY(hipStreamSynchronize(ex->stream));
+        s = orbx_extract_status(ex);
+        if (s == ORBX_ERR_CAPACITY && ex->h_err->cand_overflow) continue;
+        break;
+    }
+    if (s != ORBX_OK) return s;
+    int counts[2];
+    ORBX_HIP_TRY(hipMemcpy(counts, ex->d_counts, sizeof(counts), hipMemcpyDeviceToHost));
+    *n_out = counts[0]; *mono_index_out = counts[1];
+    if (counts[0] > capacity) { orbx_set_error("%d keypoints, capacity is %d", counts[0], capacity); return ORBX_ERR_CAPACITY; }
+    if (counts[0] > 0) {
+        ORBX_REQUIRE(keypoints && descriptors, "null output buffer");
+        ORBX_HIP_TRY(hipMemcpy(keypoints, ex->d_outKps, counts[0] * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
+        ORBX_HIP_TRY(hipMemcpy(descriptors, ex->d_outDesc, (size_t)counts[0] * 32, hipMemcpyDeviceToHost));
+    }
+    return ORBX_OK;
+}
+
+// accessors for the matching translation unit
+const OrbxFrameGeo* orbx_internal_geo_device(orbx_extractor* ex) { return ex->d_geo; }
+const OrbxFrameGeo* orbx_internal_geo_host(orbx_extractor* ex) { return ex->geoValid ? &ex->geo : nullptr; }
+const uint8_t* orbx_internal_pyramid(orbx_extractor* ex) { return ex->d_pyr; }
+hipStream_t orbx_internal_stream(orbx_extractor* ex) { return ex->stream; }
+int orbx_internal_device(orbx_extractor* ex) { return ex->device; }
+int orbx_internal_max_batch(orbx_extractor* ex) { return ex->prm.max_batch; }
+void* orbx_internal_scratch(orbx_extractor* ex, size_t bytes) {
+    if (bytes > ex->scratchAlloc) {
+        hipStreamSynchronize(ex->stream);
+        hipDeviceSynchronize();
+        if (ex->d_scratch) hipFree(ex->d_scratch);
+        ex->d_scratch = nullptr; ex->scratchAlloc = 0;
+        if (hipMalloc(&ex->d_scratch, bytes) != hipSuccess) return nullptr;
+        ex->scratchAlloc = bytes;
+    }
+    return ex->d_scratch;
+}
+
+extern "C" orbx_status orbx_pyramid_level_device(orbx_extractor* ex, int frame, int level, const uint8_t** d_ptr,
+                                                 int* width, int* height, ptrdiff_t* pitch) {
+    ORBX_REQUIRE(ex && ex->geoValid, "no geometry yet");
+    ORBX_REQUIRE(frame >= 0 && frame < ex->prm.max_batch && level >= 0 && level < ex->geo.nlevels, "bad frame / level");
+    const OrbxLevelGeo& L = ex->geo.lv[level];
+    if (d_ptr) *d_ptr = ex->d_pyr + (size_t)frame * ex->geo.pyrBytes + L.off;
+    if (width) *width = L.w;
+    if (height) *height = L.h;
+    if (pitch) *pitch = L.pitch;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t* out, size_t capacity,
+                                          int* width, int* height) {
+    const uint8_t* d = nullptr;
+    int w = 0, h = 0;
+    ptrdiff_t pitch = 0;
+    orbx_status s = orbx_pyramid_level_device(ex, frame, level, &d, &w, &h, &pitch);
+    if (s != ORBX_OK) return s;
+    if (width) *width = w;
+    if (height) *height = h;
+    if (!out) return ORBX_OK;
+    if (capacity < (size_t)w * h) { orbx_set_error("buffer too small for a %dx%d level", w, h); return ORBX_ERR_CAPACITY; }
+    ORBX_HIP_TRY(hipSetDevice(ex->device));
+    ORBX_HIP_TRY(hipStreamSynchronize(ex->stream));
+    ORBX_HIP_TRY(hipMemcpy2D(out, w, d, pitch, w, h, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_debug_level_candidates(orbx_extractor* ex, int frame, int level, float* xyr,
+                                                   uint32_t* order_key, int capacity, int* n_out) {
+    ORBX_REQUIRE(ex && ex->geoValid && n_out, "bad argument");
+    ORBX_REQUIRE(frame >= 0 && frame < ex->prm.max_batch && level >= 0 && level < ex->geo.nlevels, "bad frame / level");
+    ORBX_HIP_TRY(hipSetDevice(ex->device));
+    ORBX_HIP_TRY(hipDeviceSynchronize());
+    int n = 0;
+    ORBX_HIP_TRY(hipMemcpy(&n, ex->d_candCount + frame * ex->geo.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    const OrbxLevelGeo& L = ex->geo.lv[level];
+    n = std::min(n, L.candCap);
+    *n_out = n;
+    if (n > capacity) { orbx_set_error("capacity %d < %d candidates", capacity, n); return ORBX_ERR_CAPACITY; }
+    std::vector<OrbxCand> c(n);
+    if (n) ORBX_HIP_TRY(hipMemcpy(c.data(), ex->d_cands + (size_t)frame * ex->geo.candTotal + L.candOff, n * sizeof(OrbxCand), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        xyr[3 * i] = c[i].x; xyr[3 * i + 1] = c[i].y; xyr[3 * i + 2] = c[i].response;
+        order_key[i] = c[i].order;
+    }
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_debug_level_keypoints(orbx_extractor* ex, int frame, int level, float* xyr, int capacity,
+                                                  int* n_out) {
+    ORBX_REQUIRE(ex && ex->geoValid && n_out, "bad argument");
+    ORBX_REQUIRE(frame >= 0 && frame < ex->prm.max_batch && level >= 0 && level < ex->geo.nlevels, "bad frame / level");
+    ORBX_HIP_TRY(hipSetDevice(ex->device));
+    ORBX_HIP_TRY(hipDeviceSynchronize());
+    int n = 0;
+    ORBX_HIP_TRY(hipMemcpy(&n, ex->d_kpCount + frame * ex->geo.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (n > capacity) { orbx_set_error("capacity %d < %d keypoints", capacity, n); return ORBX_ERR_CAPACITY; }
+    const OrbxLevelGeo& L = ex->geo.lv[level];
+    std::vector<OrbxLevelKp> k(n);
+    if (n) ORBX_HIP_TRY(hipMemcpy(k.data(), ex->d_levelKps + (size_t)frame * ex->geo.kpTotal + L.kpOff, n * sizeof(OrbxLevelKp), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) { xyr[3 * i] = k[i].x; xyr[3 * i + 1] = k[i].y; xyr[3 * i + 2] = k[i].response; }
+    return ORBX_OK;
+}

@@ -7,8 +7,9 @@
 // is split first depends on the exact permutation the library's algorithm produces, so the
 // device must reproduce that algorithm step for step, not merely "a sort".
 //
-// Elements are 64-bit words; the ordering looks only at the upper 32 bits
-// (key = count << 16 | UL.x), the lower 32 bits are payload that travels with the element.
+// Elements are 64-bit words; the ordering looks only at the upper 40 bits
+// (key = key count << 16 | UL.x), the lower 24 bits are payload (the node's list position)
+// that travels with the element.
 #ifndef ORBX_INTROSORT_H_
 #define ORBX_INTROSORT_H_
 
@@ -24,7 +25,12 @@ namespace orbx_sort {
 
 typedef unsigned long long elem_t;
 
-ORBX_HD inline bool less(elem_t a, elem_t b) { return (uint32_t)(a >> 32) < (uint32_t)(b >> 32); }
+constexpr int kPayloadBits = 24;
+ORBX_HD inline elem_t make_elem(uint32_t count, uint32_t ulx, uint32_t payload) {
+    return ((elem_t)count << 40) | ((elem_t)(ulx & 0xFFFFu) << kPayloadBits) | (payload & 0xFFFFFFu);
+}
+ORBX_HD inline uint32_t payload_of(elem_t e) { return (uint32_t)(e & 0xFFFFFFu); }
+ORBX_HD inline bool less(elem_t a, elem_t b) { return (a >> kPayloadBits) < (b >> kPayloadBits); }
 ORBX_HD inline void swap_at(elem_t* v, int i, int j) { elem_t t = v[i]; v[i] = v[j]; v[j] = t; }
 
 ORBX_HD inline void unguarded_linear_insert(elem_t* v, int last) {
@@ -128,10 +134,14 @@ ORBX_HD inline int floor_log2(int n) {
 // std::sort(v, v + n, less).  __introsort_loop recurses into the right part and iterates
 // on the left part; the two parts are disjoint, so the order in which they are finished
 // does not change the result and the recursion becomes a stack of pending segments.
-ORBX_HD inline void sort(elem_t* v, int n) {
+// `stack` holds 3 * kStackDepth ints of working storage (LDS on the device).
+constexpr int kStackDepth = 72;
+ORBX_HD inline void sort(elem_t* v, int n, int* stack) {
     if (n <= 0) return;
     const int kThreshold = 16;
-    int seg_first[72], seg_last[72], seg_depth[72];
+    int* seg_first = stack;
+    int* seg_last = stack + kStackDepth;
+    int* seg_depth = stack + 2 * kStackDepth;
     int sp = 0;
     seg_first[0] = 0; seg_last[0] = n; seg_depth[0] = 2 * floor_log2(n);
     sp = 1;

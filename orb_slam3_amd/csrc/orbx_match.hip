@@ -1,0 +1,740 @@
+// Hamming descriptor matching on gfx950.  Restates
+//   ORBmatcher::DescriptorDistance                      src/ORBmatcher.cc:2141-2157
+//   cv::BFMatcher(NORM_HAMMING).knnMatch(.., 2)         src/Frame.cc:46, :1309
+//   Frame::ComputeStereoMatches                         src/Frame.cc:962-1133
+//   Frame::GetFeaturesInArea + the candidate loop of
+//   ORBmatcher::SearchByProjection                      src/Frame.cc:792-858, src/ORBmatcher.cc:84-141
+//   distance core of ORBmatcher::SearchForTriangulation src/ORBmatcher.cc:1051-1167
+//
+// Everything here is 256-bit XOR + popcount and small integer reductions: VALU work
+// (v_xor_b32 + v_bcnt_u32_b32), no matrix cores.
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "orbx_common.h"
+
+// --------------------------------------------------------------------------------------
+// small RAII helper for the synchronous host entry points
+// --------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    ~DevBuf() { if (p) hipFree(p); }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+}  // namespace
+
+__device__ __forceinline__ int hamming256(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b) {
+    int d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d += __popc(a[k] ^ b[k]);
+    return d;
+}
+
+// ======================================================================================
+// DescriptorDistance for n pairs
+// ======================================================================================
+__global__ void k_pair_distance(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, int n, int* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = hamming256(a + 8ll * i, b + 8ll * i);
+}
+
+extern "C" orbx_status orbx_descriptor_distance(const uint8_t* a, const uint8_t* b, int n, int* out) {
+    ORBX_REQUIRE(n >= 0 && (n == 0 || (a && b && out)), "bad argument");
+    if (n == 0) return ORBX_OK;
+    DevBuf da, db, dout;
+    ORBX_HIP_TRY(da.alloc((size_t)n * 32)); ORBX_HIP_TRY(db.alloc((size_t)n * 32)); ORBX_HIP_TRY(dout.alloc((size_t)n * 4));
+    ORBX_HIP_TRY(hipMemcpy(da.p, a, (size_t)n * 32, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(db.p, b, (size_t)n * 32, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_pair_distance, dim3((n + 255) / 256), dim3(256), 0, 0, da.as<uint32_t>(), db.as<uint32_t>(), n,
+                       dout.as<int>());
+    ORBX_HIP_TRY(hipGetLastError());
+    ORBX_HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// ======================================================================================
+// Brute-force 2-nearest-neighbour search.
+//
+// Each lane owns kQpl query descriptors in registers (8 VGPRs each) together with their
+// running best / second best.  Train descriptors are wave-uniform: they are fetched with
+// scalar loads and applied to all 64 x kQpl queries of the wave, so the inner loop is
+// 8 x (v_xor_b32 with an SGPR operand + v_bcnt_u32_b32 accumulate) per pair and one compare.
+// The train set is cut into contiguous chunks (grid.y); every (query group, chunk) writes a
+// partial top-2 with global indices and k_knn2_merge folds the chunks in index order.
+// Ties: strict '<' while scanning ascending indices keeps the lowest index, and the merge
+// is lexicographic on (distance, index), which is what a single sequential scan gives.
+// ======================================================================================
+constexpr int kQpl = 2;
+constexpr int kKnnWaves = 4;
+
+__global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restrict__ query, int nq,
+                                                          const uint32_t* __restrict__ train, long long nt,
+                                                          long long chunkLen, long long baseIndex,
+                                                          orbx_match2* __restrict__ part) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int group = blockIdx.x * kKnnWaves + wave;
+    const long long j0 = (long long)blockIdx.y * chunkLen;
+    const long long j1 = min(nt, j0 + chunkLen);
+
+    uint32_t q[kQpl][8];
+    int best[kQpl], second[kQpl], bestIdx[kQpl], secondIdx[kQpl];
+    int qi[kQpl];
+#pragma unroll
+    for (int i = 0; i < kQpl; ++i) {
+        qi[i] = group * 64 * kQpl + i * 64 + lane;
+        const bool ok = qi[i] < nq;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[i][k] = ok ? query[8ll * qi[i] + k] : 0u;
+        best[i] = INT_MAX; second[i] = INT_MAX; bestIdx[i] = -1; secondIdx[i] = -1;
+    }
+    if (group * 64 * kQpl >= nq) return;
+
+    for (long long j = j0; j < j1; ++j) {
+        const uint32_t* __restrict__ t = train + 8ll * j;   // wave-uniform address: scalar loads
+        uint32_t tw[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tw[k] = t[k];
+        const int gj = (int)(baseIndex + j);
+#pragma unroll
+        for (int i = 0; i < kQpl; ++i) {
+            int d = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d += __popc(q[i][k] ^ tw[k]);
+            if (d < second[i]) {
+                if (d < best[i]) { second[i] = best[i]; secondIdx[i] = bestIdx[i]; best[i] = d; bestIdx[i] = gj; }
+                else { second[i] = d; secondIdx[i] = gj; }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < kQpl; ++i) {
+        if (qi[i] < nq) {
+            orbx_match2 m;
+            m.idx0 = bestIdx[i]; m.dist0 = best[i]; m.idx1 = secondIdx[i]; m.dist1 = second[i];
+            part[(long long)blockIdx.y * nq + qi[i]] = m;
+        }
+    }
+}
+
+__device__ __forceinline__ bool lex_less(int d0, int i0, int d1, int i1) { return d0 < d1 || (d0 == d1 && i0 < i1); }
+
+__global__ void k_knn2_merge(const orbx_match2* __restrict__ part, int nParts, int nq, orbx_match2* __restrict__ out) {
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    int b = INT_MAX, bi = -1, s = INT_MAX, si = -1;
+    for (int p = 0; p < nParts; ++p) {
+        const orbx_match2 m = part[(long long)p * nq + qi];
+        const int cd[2] = {m.dist0, m.dist1}, ci[2] = {m.idx0, m.idx1};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (ci[e] < 0) continue;
+            if (bi < 0 || lex_less(cd[e], ci[e], b, bi)) { s = b; si = bi; b = cd[e]; bi = ci[e]; }
+            else if (si < 0 || lex_less(cd[e], ci[e], s, si)) { s = cd[e]; si = ci[e]; }
+        }
+    }
+    orbx_match2 m;
+    m.idx0 = bi; m.dist0 = b; m.idx1 = si; m.dist1 = s;
+    out[qi] = m;
+}
+
+static int knn2_chunks(int nq, long long nt) {
+    const int groups = (nq + 64 * kQpl - 1) / (64 * kQpl);
+    // aim for >= 8192 waves on the chip, at least 256 train rows per chunk
+    long long want = (8192 + groups - 1) / std::max(groups, 1);
+    long long maxByLen = std::max<long long>(1, nt / 256);
+    long long c = std::max<long long>(1, std::min(want, maxByLen));
+    return (int)std::min<long long>(c, 4096);
+}
+
+extern "C" size_t orbx_knn2_workspace_bytes(int n_query, int64_t n_train) {
+    if (n_query <= 0 || n_train <= 0) return 16;
+    return (size_t)knn2_chunks(n_query, n_train) * (size_t)n_query * sizeof(orbx_match2);
+}
+
+extern "C" orbx_status orbx_hamming_knn2_device(const uint8_t* d_query, int n_query, const uint8_t* d_train,
+                                                int64_t n_train, int64_t base_index, orbx_match2* d_out,
+                                                void* d_workspace, size_t workspace_bytes, void* stream) {
+    ORBX_REQUIRE(n_query >= 0 && n_train >= 0, "negative size");
+    if (n_query == 0) return ORBX_OK;
+    ORBX_REQUIRE(d_query && d_out && (n_train == 0 || d_train), "null argument");
+    ORBX_REQUIRE(base_index >= 0 && base_index + n_train <= (int64_t)INT_MAX, "train index does not fit 32 bits");
+    ORBX_REQUIRE((((uintptr_t)d_query | (uintptr_t)d_train) & 3) == 0, "descriptors must be 4-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int chunks = n_train > 0 ? knn2_chunks(n_query, n_train) : 0;
+    if (chunks > 0) {
+        ORBX_REQUIRE(d_workspace && workspace_bytes >= (size_t)chunks * n_query * sizeof(orbx_match2), "workspace too small");
+        const long long chunkLen = (n_train + chunks - 1) / chunks;
+        const int groups = (n_query + 64 * kQpl - 1) / (64 * kQpl);
+        dim3 grid((groups + kKnnWaves - 1) / kKnnWaves, chunks);
+        hipLaunchKernelGGL(k_knn2, grid, dim3(64 * kKnnWaves), 0, st, (const uint32_t*)d_query, n_query,
+                           (const uint32_t*)d_train, (long long)n_train, chunkLen, (long long)base_index,
+                           (orbx_match2*)d_workspace);
+    }
+    hipLaunchKernelGGL(k_knn2_merge, dim3((n_query + 255) / 256), dim3(256), 0, st, (const orbx_match2*)d_workspace, chunks,
+                       n_query, d_out);
+    ORBX_HIP_TRY(hipGetLastError());
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_knn2_merge_device(const orbx_match2* d_parts, int n_parts, int n_query, orbx_match2* d_out,
+                                              void* stream) {
+    ORBX_REQUIRE(n_parts >= 0 && n_query >= 0, "negative size");
+    if (n_query == 0) return ORBX_OK;
+    ORBX_REQUIRE(d_parts && d_out, "null argument");
+    hipLaunchKernelGGL(k_knn2_merge, dim3((n_query + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_parts, n_parts,
+                       n_query, d_out);
+    ORBX_HIP_TRY(hipGetLastError());
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_hamming_knn2(const uint8_t* query, int n_query, const uint8_t* train, int64_t n_train,
+                                         orbx_match2* out) {
+    ORBX_REQUIRE(n_query >= 0 && n_train >= 0, "negative size");
+    if (n_query == 0) return ORBX_OK;
+    ORBX_REQUIRE(query && out && (n_train == 0 || train), "null argument");
+    DevBuf dq, dt, dout, dws;
+    const size_t ws = orbx_knn2_workspace_bytes(n_query, n_train);
+    ORBX_HIP_TRY(dq.alloc((size_t)n_query * 32)); ORBX_HIP_TRY(dt.alloc((size_t)n_train * 32));
+    ORBX_HIP_TRY(dout.alloc((size_t)n_query * sizeof(orbx_match2))); ORBX_HIP_TRY(dws.alloc(ws));
+    ORBX_HIP_TRY(hipMemcpy(dq.p, query, (size_t)n_query * 32, hipMemcpyHostToDevice));
+    if (n_train) ORBX_HIP_TRY(hipMemcpy(dt.p, train, (size_t)n_train * 32, hipMemcpyHostToDevice));
+    orbx_status s = orbx_hamming_knn2_device(dq.as<uint8_t>(), n_query, dt.as<uint8_t>(), n_train, 0, dout.as<orbx_match2>(),
+                                             dws.p, ws, nullptr);
+    if (s != ORBX_OK) return s;
+    ORBX_HIP_TRY(hipDeviceSynchronize());
+    ORBX_HIP_TRY(hipMemcpy(out, dout.p, (size_t)n_query * sizeof(orbx_match2), hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// ======================================================================================
+// Frame::ComputeStereoMatches: one wave per left keypoint.
+//   (a) best right keypoint on the same row band / neighbouring octave / disparity range
+//   (b) 11x11 SAD over 11 horizontal shifts on the keypoint's pyramid level, parabola fit
+// then one workgroup per frame rejects matches whose SAD is >= 2.1 x the median SAD.
+// ======================================================================================
+struct OrbxPyrView {
+    const uint8_t* left;
+    const uint8_t* right;
+    long long frameStride;      // bytes between frames (same for both: same geometry)
+};
+
+__global__ __launch_bounds__(256) void k_stereo_rows(const OrbxFrameGeo* __restrict__ geo, OrbxPyrView pv,
+                                                     const orbx_keypoint* __restrict__ kpsL, const uint32_t* __restrict__ descL,
+                                                     const int* __restrict__ countsL,
+                                                     const orbx_keypoint* __restrict__ kpsR, const uint32_t* __restrict__ descR,
+                                                     const int* __restrict__ countsR, int capacity, float mbf, float mb,
+                                                     float* __restrict__ uRight, float* __restrict__ depth,
+                                                     int* __restrict__ sadOut) {
+    const int frame = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nL = countsL[2 * frame], nR = countsR[2 * frame];
+    if (iL >= nL) return;
+    const long long rowL = (long long)frame * capacity + iL;
+    const orbx_keypoint kp = kpsL[rowL];
+    const int levelL = kp.octave;
+    const float vL = kp.y, uL = kp.x;
+    const int nRows = geo->lv[0].h;
+    const float minZ = mb, minD = 0.f;
+    const float maxD = __fdiv_rn(mbf, minZ);
+    const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
+
+    if (lane == 0) { uRight[rowL] = -1.f; depth[rowL] = -1.f; sadOut[rowL] = -1; }
+    const long long rowInt = (long long)vL;   // vRowIndices[vL]: float -> size_t
+    if (rowInt < 0 || rowInt >= nRows) return;
+    if (maxU < 0) return;
+
+    const uint32_t* dL = descL + rowL * 8;
+    uint32_t ql[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ql[k] = dL[k];
+    // (a) lexicographic min over (distance, right index) of the gated candidates
+    unsigned int bestKey = 0xFFFFFFFFu;
+    for (int iR = lane; iR < nR; iR += 64) {
+        const long long rowR = (long long)frame * capacity + iR;
+        const orbx_keypoint kr = kpsR[rowR];
+        const float r = __fmul_rn(2.0f, geo->lv[kr.octave].scale);
+        const int maxr = (int)ceilf(__fadd_rn(kr.y, r));
+        const int minr = (int)floorf(__fsub_rn(kr.y, r));
+        if (rowInt < minr || rowInt > maxr) continue;
+        if (kr.octave < levelL - 1 || kr.octave > levelL + 1) continue;
+        if (!(kr.x >= minU && kr.x <= maxU)) continue;
+        const uint32_t* dR = descR + rowR * 8;
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d += __popc(ql[k] ^ dR[k]);
+        if (d < 100) bestKey = min(bestKey, ((unsigned int)d << 20) | (unsigned int)iR);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) bestKey = min(bestKey, (unsigned int)__shfl_xor((int)bestKey, off));
+    if (bestKey == 0xFFFFFFFFu) return;
+    const int bestDist = (int)(bestKey >> 20), bestIdxR = (int)(bestKey & 0xFFFFFu);
+    if (!(bestDist < 75)) return;   // thOrbDist = (TH_HIGH + TH_LOW) / 2
+
+    // (b) sub-pixel refinement by correlation on the pyramid level of the left keypoint
+    const OrbxLevelGeo& G = geo->lv[levelL];
+    const float uR0 = kpsR[(long long)frame * capacity + bestIdxR].x;
+    const float sInv = G.invScale;
+    const float suL = roundf(__fmul_rn(kp.x, sInv)), svL = roundf(__fmul_rn(kp.y, sInv)), suR0 = roundf(__fmul_rn(uR0, sInv));
+    const int w = 5, L = 5;
+    const float iniu = __fsub_rn(__fadd_rn(suR0, (float)L), (float)w);
+    const float endu = __fadd_rn(__fadd_rn(__fadd_rn(suR0, (float)L), (float)w), 1.f);
+    if (iniu < 0 || endu >= (float)G.w) return;
+    const uint8_t* imL = pv.left + (long long)frame * pv.frameStride + G.off;
+    const uint8_t* imR = pv.right + (long long)frame * pv.frameStride + G.off;
+    const int y0 = (int)(svL - w), xl0 = (int)(suL - w), xr0 = (int)(suR0 - w);
+    int sad[11];
+#pragma unroll
+    for (int s = 0; s < 11; ++s) sad[s] = 0;
+    for (int p = lane; p < 121; p += 64) {
+        const int dy = p / 11, dx = p - dy * 11;
+        const int a = imL[(long long)(y0 + dy) * G.pitch + xl0 + dx];
+        const uint8_t* rrow = imR + (long long)(y0 + dy) * G.pitch + xr0 + dx;
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+            const int b = rrow[s - L];
+            sad[s] += abs(a - b);
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 11; ++s) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sad[s] += __shfl_xor(sad[s], off);
+    }
+    if (lane != 0) return;
+    int bestSad = INT_MAX, bestInc = 0;
+#pragma unroll
+    for (int s = 0; s < 11; ++s)
+        if (sad[s] < bestSad) { bestSad = sad[s]; bestInc = s - L; }
+    if (bestInc == -L || bestInc == L) return;
+    float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+    for (int s = 1; s < 10; ++s)
+        if (s - L == bestInc) { d1 = (float)sad[s - 1]; d2 = (float)sad[s]; d3 = (float)sad[s + 1]; }
+    const float delta = __fdiv_rn(__fsub_rn(d1, d3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+    if (delta < -1 || delta > 1) return;
+    float bestuR = __fmul_rn(G.scale, __fadd_rn(__fadd_rn(suR0, (float)bestInc), delta));
+    float disparity = __fsub_rn(uL, bestuR);
+    if (disparity >= minD && disparity < maxD) {
+        if (disparity <= 0) {
+            disparity = 0.01f;                              // float(0.01)
+            bestuR = (float)((double)uL - 0.01);            // uL - 0.01 in double, then to float
+        }
+        depth[rowL] = __fdiv_rn(mbf, disparity);
+        uRight[rowL] = bestuR;
+        sadOut[rowL] = bestSad;
+    }
+}
+
+// Median cut: threshold = 1.5f * 1.4f * (SAD of the (count/2)-th match in (SAD, index) order).
+__global__ __launch_bounds__(256) void k_stereo_median(const int* __restrict__ countsL, int capacity,
+                                                       float* __restrict__ uRight, float* __restrict__ depth,
+                                                       const int* __restrict__ sad) {
+    __shared__ int hist[256];
+    __shared__ int s_bin, s_rank, s_cnt, s_median;
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int nL = countsL[2 * frame];
+    const long long base = (long long)frame * capacity;
+    // pass 1: high part of the SAD (121 * 255 < 2^15)
+    hist[tid] = 0;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    int local = 0;
+    for (int i = tid; i < nL; i += 256) {
+        const int v = sad[base + i];
+        if (v >= 0) { atomicAdd(&hist[v >> 7], 1); ++local; }
+    }
+    if (local) atomicAdd(&s_cnt, local);
+    __syncthreads();
+    const int cnt = s_cnt;
+    if (cnt == 0) return;
+    if (tid == 0) {
+        int k = cnt / 2, acc = 0, b = 0;
+        for (; b < 256; ++b) { if (acc + hist[b] > k) break; acc += hist[b]; }
+        s_bin = b; s_rank = k - acc;
+    }
+    __syncthreads();
+    const int bin = s_bin, rank = s_rank;
+    __syncthreads();
+    hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < nL; i += 256) {
+        const int v = sad[base + i];
+        if (v >= 0 && (v >> 7) == bin) atomicAdd(&hist[v & 127], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, b = 0;
+        for (; b < 128; ++b) { if (acc + hist[b] > rank) break; acc += hist[b]; }
+        s_median = (bin << 7) | b;
+    }
+    __syncthreads();
+    const float median = (float)s_median;
+    const float thDist = __fmul_rn(1.5f * 1.4f, median);
+    for (int i = tid; i < nL; i += 256) {
+        const int v = sad[base + i];
+        if (v >= 0 && !((float)v < thDist)) { uRight[base + i] = -1.f; depth[base + i] = -1.f; }
+    }
+}
+
+// geometry accessors implemented in orbx_extract.hip
+extern "C" orbx_status orbx_pyramid_level_device(orbx_extractor*, int, int, const uint8_t**, int*, int*, ptrdiff_t*);
+const OrbxFrameGeo* orbx_internal_geo_device(orbx_extractor* ex);
+const OrbxFrameGeo* orbx_internal_geo_host(orbx_extractor* ex);
+const uint8_t* orbx_internal_pyramid(orbx_extractor* ex);
+hipStream_t orbx_internal_stream(orbx_extractor* ex);
+int orbx_internal_device(orbx_extractor* ex);
+int orbx_internal_max_batch(orbx_extractor* ex);
+void* orbx_internal_scratch(orbx_extractor* ex, size_t bytes);
+
+extern "C" orbx_status orbx_stereo_match_batch_device(orbx_extractor* left, orbx_extractor* right, int n_frames,
+                                                      const orbx_keypoint* d_kps_left, const uint8_t* d_desc_left,
+                                                      const int* d_counts_left, const orbx_keypoint* d_kps_right,
+                                                      const uint8_t* d_desc_right, const int* d_counts_right, int capacity,
+                                                      float mbf, float mb, float* d_u_right, float* d_depth, void* stream) {
+    ORBX_REQUIRE(left && right && d_kps_left && d_desc_left && d_counts_left && d_kps_right && d_desc_right &&
+                 d_counts_right && d_u_right && d_depth, "null argument");
+    const OrbxFrameGeo* gl = orbx_internal_geo_host(left);
+    const OrbxFrameGeo* gr = orbx_internal_geo_host(right);
+    ORBX_REQUIRE(gl && gr, "extractors have not processed an image yet");
+    ORBX_REQUIRE(gl->w == gr->w && gl->h == gr->h && gl->nlevels == gr->nlevels && gl->pyrBytes == gr->pyrBytes,
+                 "left and right extractors must have the same geometry");
+    ORBX_REQUIRE(n_frames >= 1 && n_frames <= orbx_internal_max_batch(left) && n_frames <= orbx_internal_max_batch(right),
+                 "bad n_frames");
+    ORBX_REQUIRE(capacity >= 1 && capacity < (1 << 20), "bad capacity");
+    ORBX_REQUIRE(mb > 0.f, "baseline must be positive");
+    ORBX_HIP_TRY(hipSetDevice(orbx_internal_device(left)));
+    hipStream_t st = stream ? (hipStream_t)stream : orbx_internal_stream(left);
+    OrbxPyrView pv;
+    pv.left = orbx_internal_pyramid(left);
+    pv.right = orbx_internal_pyramid(right);
+    pv.frameStride = gl->pyrBytes;
+    int* d_sad = (int*)orbx_internal_scratch(left, (size_t)n_frames * capacity * sizeof(int));
+    if (!d_sad) { orbx_set_error("cannot allocate the SAD scratch buffer"); return ORBX_ERR_HIP; }
+    hipLaunchKernelGGL(k_stereo_rows, dim3((capacity + 3) / 4, n_frames), dim3(256), 0, st, orbx_internal_geo_device(left), pv,
+                       d_kps_left, (const uint32_t*)d_desc_left, d_counts_left, d_kps_right, (const uint32_t*)d_desc_right,
+                       d_counts_right, capacity, mbf, mb, d_u_right, d_depth, d_sad);
+    hipLaunchKernelGGL(k_stereo_median, dim3(n_frames), dim3(256), 0, st, d_counts_left, capacity, d_u_right, d_depth, d_sad);
+    ORBX_HIP_TRY(hipGetLastError());
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_stereo_match(orbx_extractor* left, orbx_extractor* right, int frame,
+                                         const orbx_keypoint* kps_left, const uint8_t* desc_left, int n_left,
+                                         const orbx_keypoint* kps_right, const uint8_t* desc_right, int n_right, float mbf,
+                                         float mb, float* u_right, float* depth) {
+    ORBX_REQUIRE(left && right && n_left >= 0 && n_right >= 0, "bad argument");
+    ORBX_REQUIRE(frame == 0, "the host entry point matches batch slot 0");
+    if (n_left == 0) return ORBX_OK;
+    ORBX_REQUIRE(kps_left && desc_left && u_right && depth && (n_right == 0 || (kps_right && desc_right)), "null argument");
+    ORBX_HIP_TRY(hipSetDevice(orbx_internal_device(left)));
+    const int cap = std::max(std::max(n_left, n_right), 1);
+    DevBuf kl, dl, kr, dr, cl, cr, ur, dp;
+    ORBX_HIP_TRY(kl.alloc((size_t)cap * sizeof(orbx_keypoint))); ORBX_HIP_TRY(dl.alloc((size_t)cap * 32));
+    ORBX_HIP_TRY(kr.alloc((size_t)cap * sizeof(orbx_keypoint))); ORBX_HIP_TRY(dr.alloc((size_t)cap * 32));
+    ORBX_HIP_TRY(cl.alloc(8)); ORBX_HIP_TRY(cr.alloc(8));
+    ORBX_HIP_TRY(ur.alloc((size_t)cap * 4)); ORBX_HIP_TRY(dp.alloc((size_t)cap * 4));
+    const int cL[2] = {n_left, 0}, cR[2] = {n_right, 0};
+    ORBX_HIP_TRY(hipMemcpy(kl.p, kps_left, (size_t)n_left * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(dl.p, desc_left, (size_t)n_left * 32, hipMemcpyHostToDevice));
+    if (n_right) {
+        ORBX_HIP_TRY(hipMemcpy(kr.p, kps_right, (size_t)n_right * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
+        ORBX_HIP_TRY(hipMemcpy(dr.p, desc_right, (size_t)n_right * 32, hipMemcpyHostToDevice));
+    }
+    ORBX_HIP_TRY(hipMemcpy(cl.p, cL, 8, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(cr.p, cR, 8, hipMemcpyHostToDevice));
+    hipStream_t st = orbx_internal_stream(left);
+    ORBX_HIP_TRY(hipStreamSynchronize(orbx_internal_stream(right)));
+    orbx_status s = orbx_stereo_match_batch_device(left, right, 1, kl.as<orbx_keypoint>(), dl.as<uint8_t>(), cl.as<int>(),
+                                                   kr.as<orbx_keypoint>(), dr.as<uint8_t>(), cr.as<int>(), cap, mbf, mb,
+                                                   ur.as<float>(), dp.as<float>(), st);
+    if (s != ORBX_OK) return s;
+    ORBX_HIP_TRY(hipStreamSynchronize(st));
+    ORBX_HIP_TRY(hipMemcpy(u_right, ur.p, (size_t)n_left * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_TRY(hipMemcpy(depth, dp.p, (size_t)n_left * 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// ======================================================================================
+// Windowed candidate search (GetFeaturesInArea + per-candidate distance)
+// ======================================================================================
+constexpr int kGridCols = 64, kGridRows = 48;   // FRAME_GRID_COLS / FRAME_GRID_ROWS (Frame.h:43-44)
+
+struct OrbxGridDev {
+    const int* cellStart;     // kGridCols * kGridRows + 1, cell = ix * kGridRows + iy
+    const int* cellIdx;       // keypoint indices, insertion (ascending) order inside a cell
+    float minX, minY, invW, invH;
+};
+
+// One wave per query.  mode 0: count candidates; mode 1: write them at candOffset[q].
+__global__ __launch_bounds__(256) void k_window(OrbxGridDev g, const orbx_keypoint* __restrict__ kps,
+                                                const uint32_t* __restrict__ desc, const float* __restrict__ uright,
+                                                const orbx_query* __restrict__ queries, const uint32_t* __restrict__ qdesc,
+                                                int nq, int mode, int* __restrict__ candCount,
+                                                const int* __restrict__ candOffset, int* __restrict__ candIdx,
+                                                int* __restrict__ candDist) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const orbx_query Q = queries[q];
+    const float r = Q.radius;
+    int total = 0;
+    const int minCX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.x, g.minX), r), g.invW)));
+    const int maxCX = min(kGridCols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.x, g.minX), r), g.invW)));
+    const int minCY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(Q.y, g.minY), r), g.invH)));
+    const int maxCY = min(kGridRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(Q.y, g.minY), r), g.invH)));
+    const bool empty = (minCX >= kGridCols) || (maxCX < 0) || (minCY >= kGridRows) || (maxCY < 0);
+    const bool checkLevels = (Q.min_level > 0) || (Q.max_level >= 0);
+    uint32_t qd[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qd[k] = qdesc[8ll * q + k];
+    const int outBase = (mode == 1) ? candOffset[q] : 0;
+    if (!empty) {
+        for (int ix = minCX; ix <= maxCX; ++ix) {
+            // cells (ix, minCY..maxCY) are contiguous in the CSR
+            const int b = g.cellStart[ix * kGridRows + minCY], e = g.cellStart[ix * kGridRows + maxCY + 1];
+            for (int c0 = b; c0 < e; c0 += 64) {
+                const int c = c0 + lane;
+                bool ok = false;
+                int idx = -1;
+                if (c < e) {
+                    idx = g.cellIdx[c];
+                    const orbx_keypoint kp = kps[idx];
+                    ok = true;
+                    if (checkLevels) {
+                        if (kp.octave < Q.min_level) ok = false;
+                        if (Q.max_level >= 0 && kp.octave > Q.max_level) ok = false;
+                    }
+                    const float dx = __fsub_rn(kp.x, Q.x), dy = __fsub_rn(kp.y, Q.y);
+                    if (!(fabsf(dx) < r && fabsf(dy) < r)) ok = false;
+                    if (ok && uright != nullptr) {
+                        const float ur = uright[idx];
+                        if (ur > 0 && fabsf(__fsub_rn(Q.xr, ur)) > r) ok = false;
+                    }
+                }
+                const unsigned long long bal = __ballot(ok);
+                if (mode == 1 && ok) {
+                    const int pos = outBase + total + __popcll(bal & ((1ull << lane) - 1ull));
+                    int d = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) d += __popc(qd[k] ^ desc[8ll * idx + k]);
+                    candIdx[pos] = idx;
+                    candDist[pos] = d;
+                }
+                total += __popcll(bal);
+            }
+        }
+    }
+    if (mode == 0 && lane == 0) candCount[q] = total;
+}
+
+namespace {
+struct HostGrid {
+    std::vector<int> cellStart, cellIdx;
+    float minX, minY, invW, invH;
+};
+// Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:468-506, :860-870): ascending keypoint
+// index inside each cell; keypoints outside the bounds are left out.
+void build_grid(const orbx_keypoint* kps, int n, float minX, float maxX, float minY, float maxY, HostGrid& g) {
+    g.minX = minX; g.minY = minY;
+    g.invW = (float)kGridCols / (maxX - minX);
+    g.invH = (float)kGridRows / (maxY - minY);
+    const int nc = kGridCols * kGridRows;
+    std::vector<int> cell(n, -1);
+    g.cellStart.assign(nc + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        const int px = (int)std::round((kps[i].x - minX) * g.invW);
+        const int py = (int)std::round((kps[i].y - minY) * g.invH);
+        if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) continue;
+        cell[i] = px * kGridRows + py;
+        ++g.cellStart[cell[i] + 1];
+    }
+    for (int c = 0; c < nc; ++c) g.cellStart[c + 1] += g.cellStart[c];
+    g.cellIdx.assign(g.cellStart[nc], 0);
+    std::vector<int> cur(g.cellStart.begin(), g.cellStart.end() - 1);
+    for (int i = 0; i < n; ++i)
+        if (cell[i] >= 0) g.cellIdx[cur[cell[i]]++] = i;
+}
+}  // namespace
+
+static orbx_status window_candidates_impl(const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps,
+                                          float min_x, float max_x, float min_y, float max_y, const orbx_query* queries,
+                                          const uint8_t* query_desc, int n_query, std::vector<int>& offset,
+                                          std::vector<int>& idx, std::vector<int>& dist) {
+    ORBX_REQUIRE(n_kps >= 0 && n_query >= 0, "negative size");
+    ORBX_REQUIRE(max_x > min_x && max_y > min_y, "empty image bounds");
+    offset.assign(n_query + 1, 0);
+    idx.clear(); dist.clear();
+    if (n_query == 0 || n_kps == 0) return ORBX_OK;
+    ORBX_REQUIRE(kps && desc && queries && query_desc, "null argument");
+    HostGrid hg;
+    build_grid(kps, n_kps, min_x, max_x, min_y, max_y, hg);
+    DevBuf dStart, dIdx, dKps, dDesc, dUr, dQ, dQd, dCount, dOff, dCi, dCd;
+    ORBX_HIP_TRY(dStart.alloc(hg.cellStart.size() * 4)); ORBX_HIP_TRY(dIdx.alloc(hg.cellIdx.size() * 4));
+    ORBX_HIP_TRY(dKps.alloc((size_t)n_kps * sizeof(orbx_keypoint))); ORBX_HIP_TRY(dDesc.alloc((size_t)n_kps * 32));
+    ORBX_HIP_TRY(dUr.alloc((size_t)n_kps * 4));
+    ORBX_HIP_TRY(dQ.alloc((size_t)n_query * sizeof(orbx_query))); ORBX_HIP_TRY(dQd.alloc((size_t)n_query * 32));
+    ORBX_HIP_TRY(dCount.alloc((size_t)n_query * 4)); ORBX_HIP_TRY(dOff.alloc((size_t)(n_query + 1) * 4));
+    ORBX_HIP_TRY(hipMemcpy(dStart.p, hg.cellStart.data(), hg.cellStart.size() * 4, hipMemcpyHostToDevice));
+    if (!hg.cellIdx.empty()) ORBX_HIP_TRY(hipMemcpy(dIdx.p, hg.cellIdx.data(), hg.cellIdx.size() * 4, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(dKps.p, kps, (size_t)n_kps * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(dDesc.p, desc, (size_t)n_kps * 32, hipMemcpyHostToDevice));
+    if (uright) ORBX_HIP_TRY(hipMemcpy(dUr.p, uright, (size_t)n_kps * 4, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(dQ.p, queries, (size_t)n_query * sizeof(orbx_query), hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(dQd.p, query_desc, (size_t)n_query * 32, hipMemcpyHostToDevice));
+    OrbxGridDev g;
+    g.cellStart = dStart.as<int>(); g.cellIdx = dIdx.as<int>();
+    g.minX = hg.minX; g.minY = hg.minY; g.invW = hg.invW; g.invH = hg.invH;
+    const dim3 grid((n_query + 3) / 4), block(256);
+    hipLaunchKernelGGL(k_window, grid, block, 0, 0, g, dKps.as<orbx_keypoint>(), dDesc.as<uint32_t>(),
+                       uright ? dUr.as<float>() : nullptr, dQ.as<orbx_query>(), dQd.as<uint32_t>(), n_query, 0,
+                       dCount.as<int>(), nullptr, nullptr, nullptr);
+    ORBX_HIP_TRY(hipGetLastError());
+    std::vector<int> count(n_query);
+    ORBX_HIP_TRY(hipMemcpy(count.data(), dCount.p, (size_t)n_query * 4, hipMemcpyDeviceToHost));
+    for (int q = 0; q < n_query; ++q) offset[q + 1] = offset[q] + count[q];
+    const int total = offset[n_query];
+    idx.assign(total, 0); dist.assign(total, 0);
+    if (total == 0) return ORBX_OK;
+    ORBX_HIP_TRY(dCi.alloc((size_t)total * 4)); ORBX_HIP_TRY(dCd.alloc((size_t)total * 4));
+    ORBX_HIP_TRY(hipMemcpy(dOff.p, offset.data(), (size_t)(n_query + 1) * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_window, grid, block, 0, 0, g, dKps.as<orbx_keypoint>(), dDesc.as<uint32_t>(),
+                       uright ? dUr.as<float>() : nullptr, dQ.as<orbx_query>(), dQd.as<uint32_t>(), n_query, 1,
+                       nullptr, dOff.as<int>(), dCi.as<int>(), dCd.as<int>());
+    ORBX_HIP_TRY(hipGetLastError());
+    ORBX_HIP_TRY(hipMemcpy(idx.data(), dCi.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_TRY(hipMemcpy(dist.data(), dCd.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_window_candidates(const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps,
+                                              float min_x, float max_x, float min_y, float max_y,
+                                              const orbx_query* queries, const uint8_t* query_desc, int n_query,
+                                              int* cand_offset, int* cand_idx, int* cand_dist, int capacity,
+                                              int* n_cand_out) {
+    ORBX_REQUIRE(cand_offset && n_cand_out, "null argument");
+    std::vector<int> off, idx, dist;
+    orbx_status s = window_candidates_impl(kps, desc, uright, n_kps, min_x, max_x, min_y, max_y, queries, query_desc,
+                                           n_query, off, idx, dist);
+    if (s != ORBX_OK) return s;
+    memcpy(cand_offset, off.data(), off.size() * sizeof(int));
+    *n_cand_out = (int)idx.size();
+    if ((int)idx.size() > capacity) { orbx_set_error("%zu candidates, capacity %d", idx.size(), capacity); return ORBX_ERR_CAPACITY; }
+    if (!idx.empty()) {
+        ORBX_REQUIRE(cand_idx && cand_dist, "null argument");
+        memcpy(cand_idx, idx.data(), idx.size() * sizeof(int));
+        memcpy(cand_dist, dist.data(), dist.size() * sizeof(int));
+    }
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_search_by_projection(const orbx_keypoint* kps, const uint8_t* desc, const float* uright,
+                                                 int n_kps, float min_x, float max_x, float min_y, float max_y,
+                                                 const orbx_query* queries, const uint8_t* query_desc, int n_query,
+                                                 float nn_ratio, uint8_t* taken, int* match_out, int* n_matches) {
+    ORBX_REQUIRE(match_out && n_matches && (n_kps == 0 || taken), "null argument");
+    std::vector<int> off, idx, dist;
+    orbx_status s = window_candidates_impl(kps, desc, uright, n_kps, min_x, max_x, min_y, max_y, queries, query_desc,
+                                           n_query, off, idx, dist);
+    if (s != ORBX_OK) return s;
+    // Greedy resolve in query order (ORBmatcher.cc:84-141): a keypoint matched by an
+    // earlier map point is skipped by the later ones.
+    int nm = 0;
+    for (int q = 0; q < n_query; ++q) {
+        match_out[q] = -1;
+        int best = 256, bestLevel = -1, best2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int c = off[q]; c < off[q + 1]; ++c) {
+            const int i = idx[c];
+            if (taken[i]) continue;
+            const int d = dist[c];
+            if (d < best) { best2 = best; best = d; bestLevel2 = bestLevel; bestLevel = kps[i].octave; bestIdx = i; }
+            else if (d < best2) { bestLevel2 = kps[i].octave; best2 = d; }
+        }
+        if (bestIdx < 0) continue;
+        if (best <= 100) {
+            if (bestLevel == bestLevel2 && best > nn_ratio * best2) continue;
+            if (bestLevel != bestLevel2 || best <= nn_ratio * best2) {
+                match_out[q] = bestIdx;
+                taken[bestIdx] = 1;
+                ++nm;
+            }
+        }
+    }
+    *n_matches = nm;
+    return ORBX_OK;
+}
+
+// ======================================================================================
+// Bucketed all-pairs best match (SearchForTriangulation's distance core)
+// ======================================================================================
+__global__ __launch_bounds__(256) void k_bucket_best(const uint32_t* __restrict__ d1, const int* __restrict__ idx1,
+                                                     const int* __restrict__ off1, const uint32_t* __restrict__ d2,
+                                                     const int* __restrict__ idx2, const int* __restrict__ off2,
+                                                     const int* __restrict__ bucketOf, int n1, int* __restrict__ bestIdx2,
+                                                     int* __restrict__ bestDist) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n1) return;
+    const int b = bucketOf[i];
+    uint32_t a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = d1[8ll * idx1[i] + k];
+    // smallest distance <= 50; among equals the LAST one in bucket order
+    unsigned int key = 0xFFFFFFFFu;
+    const int jb = off2[b], je = off2[b + 1];
+    for (int j = jb + lane; j < je; j += 64) {
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d += __popc(a[k] ^ d2[8ll * idx2[j] + k]);
+        if (d <= 50) key = min(key, ((unsigned int)d << 22) | (unsigned int)(0x3FFFFF - (j - jb)));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned int)__shfl_xor((int)key, off));
+    if (lane == 0) {
+        if (key == 0xFFFFFFFFu) { bestIdx2[i] = -1; bestDist[i] = 50; }
+        else { bestDist[i] = (int)(key >> 22); bestIdx2[i] = idx2[jb + (0x3FFFFF - (int)(key & 0x3FFFFF))]; }
+    }
+}
+
+extern "C" orbx_status orbx_bucket_best(const uint8_t* desc1, int n_desc1, const int* idx1, const int* off1,
+                                        const uint8_t* desc2, int n_desc2, const int* idx2, const int* off2, int n_buckets,
+                                        int* best_idx2, int* best_dist) {
+    ORBX_REQUIRE(n_buckets >= 0 && n_desc1 >= 0 && n_desc2 >= 0, "negative size");
+    if (n_buckets == 0) return ORBX_OK;
+    ORBX_REQUIRE(off1 && off2, "null argument");
+    const int n1 = off1[n_buckets], n2 = off2[n_buckets];
+    if (n1 == 0) return ORBX_OK;
+    ORBX_REQUIRE(desc1 && idx1 && best_idx2 && best_dist && (n2 == 0 || (desc2 && idx2)), "null argument");
+    std::vector<int> bucketOf(n1);
+    for (int b = 0; b < n_buckets; ++b) {
+        ORBX_REQUIRE(off1[b + 1] >= off1[b] && off2[b + 1] >= off2[b] && off2[b + 1] - off2[b] < 0x3FFFFF, "bad bucket offsets");
+        for (int i = off1[b]; i < off1[b + 1]; ++i) bucketOf[i] = b;
+    }
+    for (int i = 0; i < n1; ++i) ORBX_REQUIRE(idx1[i] >= 0 && idx1[i] < n_desc1, "idx1 out of range");
+    for (int j = 0; j < n2; ++j) ORBX_REQUIRE(idx2[j] >= 0 && idx2[j] < n_desc2, "idx2 out of range");
+    DevBuf D1, D2, I1, I2, O1, O2, BO, BI, BD;
+    ORBX_HIP_TRY(D1.alloc((size_t)n_desc1 * 32)); ORBX_HIP_TRY(D2.alloc((size_t)n_desc2 * 32));
+    ORBX_HIP_TRY(I1.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(I2.alloc((size_t)n2 * 4));
+    ORBX_HIP_TRY(O1.alloc((size_t)(n_buckets + 1) * 4)); ORBX_HIP_TRY(O2.alloc((size_t)(n_buckets + 1) * 4));
+    ORBX_HIP_TRY(BO.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(BI.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(BD.alloc((size_t)n1 * 4));
+    ORBX_HIP_TRY(hipMemcpy(D1.p, desc1, (size_t)n_desc1 * 32, hipMemcpyHostToDevice));
+    if (n_desc2) ORBX_HIP_TRY(hipMemcpy(D2.p, desc2, (size_t)n_desc2 * 32, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(I1.p, idx1, (size_t)n1 * 4, hipMemcpyHostToDevice));
+    if (n2) ORBX_HIP_TRY(hipMemcpy(I2.p, idx2, (size_t)n2 * 4, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(O1.p, off1, (size_t)(n_buckets + 1) * 4, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(O2.p, off2, (size_t)(n_buckets + 1) * 4, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(BO.p, bucketOf.data(), (size_t)n1 * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_bucket_best, dim3((n1 + 3) / 4), dim3(256), 0, 0, D1.as<uint32_t>(), I1.as<int>(), O1.as<int>(),
+                       D2.as<uint32_t>(), I2.as<int>(), O2.as<int>(), BO.as<int>(), n1, BI.as<int>(), BD.as<int>());
+    ORBX_HIP_TRY(hipGetLastError());
+    ORBX_HIP_TRY(hipMemcpy(best_idx2, BI.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_TRY(hipMemcpy(best_dist, BD.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}

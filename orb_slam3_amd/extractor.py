@@ -1,0 +1,167 @@
+"""Python mirror of ORB_SLAM3::ORBextractor (include/ORBextractor.h:42-121) over the C ABI.
+
+Host arrays go through orbx_extract / orbx_extract_batch; torch CUDA tensors go through
+orbx_extract_batch_device (device resident, asynchronous on the current torch stream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE, RECT_DTYPE, OrbxParams, check, lib, ptr
+
+
+class ORBextractor:
+    """ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)  (ORBextractor.cc:477).
+
+    max_width / max_height / max_batch size the device buffers of the handle.
+    """
+
+    def __init__(self, nfeatures: int, scaleFactor: float, nlevels: int, iniThFAST: int, minThFAST: int,
+                 max_width: int = 752, max_height: int = 480, max_batch: int = 1, device: int = -1):
+        self._L = lib()
+        self._h = C.c_void_p()
+        self.nfeatures, self.nlevels = int(nfeatures), int(nlevels)
+        self.scaleFactor = float(np.float32(scaleFactor))
+        self.max_batch = int(max_batch)
+        p = OrbxParams(int(nfeatures), float(scaleFactor), int(nlevels), int(iniThFAST), int(minThFAST),
+                       int(max_width), int(max_height), int(max_batch), int(device))
+        check(self._L.orbx_extractor_create(C.byref(p), C.byref(self._h)))
+        n = self.nlevels
+        self.mvScaleFactor = np.zeros(n, np.float32)
+        self.mvInvScaleFactor = np.zeros(n, np.float32)
+        self.mvLevelSigma2 = np.zeros(n, np.float32)
+        self.mvInvLevelSigma2 = np.zeros(n, np.float32)
+        self.mnFeaturesPerLevel = np.zeros(n, np.int32)
+        check(self._L.orbx_extractor_tables(self._h, ptr(self.mvScaleFactor), ptr(self.mvInvScaleFactor),
+                                            ptr(self.mvLevelSigma2), ptr(self.mvInvLevelSigma2),
+                                            ptr(self.mnFeaturesPerLevel)))
+        self.max_keypoints = self._L.orbx_extractor_max_keypoints(self._h)
+        self.mvDynamicArea = []   # list of (x, y, w, h); ORBextractor.h:95-96
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.orbx_extractor_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # getters of the reference class
+    def GetLevels(self): return self.nlevels
+    def GetScaleFactor(self): return self.scaleFactor
+    def GetScaleFactors(self): return self.mvScaleFactor.copy()
+    def GetInverseScaleFactors(self): return self.mvInvScaleFactor.copy()
+    def GetScaleSigmaSquares(self): return self.mvLevelSigma2.copy()
+    def GetInverseScaleSigmaSquares(self): return self.mvInvLevelSigma2.copy()
+
+    def __call__(self, image: np.ndarray, vLappingArea=(0, 0)):
+        """operator()(image, mask, keypoints, descriptors, vLappingArea) (ORBextractor.cc:1271).
+        Returns (keypoints[KP_DTYPE], descriptors[n, 32] uint8, monoIndex); monoIndex is -1 for
+        an empty image."""
+        if image is None or image.size == 0:
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8), -1
+        assert image.dtype == np.uint8 and image.ndim == 2, "CV_8UC1 image expected"
+        if image.strides[1] != 1:
+            image = np.ascontiguousarray(image)
+        h, w = image.shape
+        cap = self.max_keypoints
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n, mono = C.c_int(), C.c_int()
+        rects = None
+        if self.mvDynamicArea:
+            rects = np.array([tuple(r) for r in self.mvDynamicArea], RECT_DTYPE)
+        check(self._L.orbx_extract(self._h, image.ctypes.data, w, h, image.strides[0], int(vLappingArea[0]),
+                                   int(vLappingArea[1]), ptr(rects), 0 if rects is None else len(rects), ptr(kps),
+                                   ptr(desc), cap, C.byref(n), C.byref(mono)))
+        return kps[:n.value].copy(), desc[:n.value].copy(), mono.value
+
+    def extract_batch(self, images, vLappingArea=(0, 0)):
+        """One pass of every kernel over a list of equally sized host images.
+        Returns a list of (keypoints, descriptors, monoIndex)."""
+        nf = len(images)
+        assert 1 <= nf <= self.max_batch
+        imgs = [np.ascontiguousarray(im) for im in images]
+        h, w = imgs[0].shape
+        assert all(im.shape == (h, w) and im.dtype == np.uint8 for im in imgs)
+        ptrs = (C.c_void_p * nf)(*[im.ctypes.data for im in imgs])
+        cap = self.max_keypoints
+        kps = np.zeros((nf, cap), KP_DTYPE)
+        desc = np.zeros((nf, cap, 32), np.uint8)
+        n = np.zeros(nf, np.int32)
+        mono = np.zeros(nf, np.int32)
+        check(self._L.orbx_extract_batch(self._h, ptrs, nf, w, h, w, int(vLappingArea[0]), int(vLappingArea[1]),
+                                         ptr(kps), ptr(desc), cap, ptr(n), ptr(mono)))
+        return [(kps[f, :n[f]].copy(), desc[f, :n[f]].copy(), int(mono[f])) for f in range(nf)]
+
+    def extract_batch_device(self, d_images, vLappingArea=(0, 0), out=None, stream=None):
+        """d_images: torch uint8 CUDA tensor [n, H, W] (row stride W, or any row/frame stride).
+        Enqueues on the current torch stream and returns (kps, desc, counts) CUDA tensors:
+        kps uint8 [n, cap, 28] (view as KP_DTYPE on the host), desc uint8 [n, cap, 32],
+        counts int32 [n, 2] = (n_keypoints, monoIndex).  Call status() after synchronising."""
+        import torch
+        assert d_images.is_cuda and d_images.dtype == torch.uint8 and d_images.dim() == 3
+        assert d_images.stride(2) == 1
+        nf, h, w = d_images.shape
+        cap = self.max_keypoints
+        if out is None:
+            kps = torch.empty((nf, cap, 28), dtype=torch.uint8, device=d_images.device)
+            desc = torch.empty((nf, cap, 32), dtype=torch.uint8, device=d_images.device)
+            counts = torch.empty((nf, 2), dtype=torch.int32, device=d_images.device)
+        else:
+            kps, desc, counts = out
+        st = torch.cuda.current_stream(d_images.device).cuda_stream if stream is None else stream
+        rects = None
+        if self.mvDynamicArea:
+            rects = np.array([tuple(r) for r in self.mvDynamicArea], RECT_DTYPE)
+        check(self._L.orbx_extract_batch_device(self._h, d_images.data_ptr(), nf, w, h, d_images.stride(1),
+                                                d_images.stride(0), int(vLappingArea[0]), int(vLappingArea[1]),
+                                                ptr(rects), 0 if rects is None else len(rects), kps.data_ptr(),
+                                                desc.data_ptr(), cap, counts.data_ptr(), st))
+        return kps, desc, counts
+
+    def status(self):
+        """Raises if the last asynchronous batch overflowed an internal buffer."""
+        check(self._L.orbx_extract_status(self._h))
+
+    def pyramid_level(self, level: int, frame: int = 0) -> np.ndarray:
+        """mvImagePyramid[level] of the last call (borderless copy)."""
+        w, h = C.c_int(), C.c_int()
+        check(self._L.orbx_pyramid_level(self._h, frame, level, None, 0, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        check(self._L.orbx_pyramid_level(self._h, frame, level, ptr(out), out.size, C.byref(w), C.byref(h)))
+        return out
+
+    def debug_level_candidates(self, level: int, frame: int = 0):
+        cap = 1 << 22
+        xyr = np.zeros((cap, 3), np.float32)
+        order = np.zeros(cap, np.uint32)
+        n = C.c_int()
+        check(self._L.orbx_debug_level_candidates(self._h, frame, level, ptr(xyr), ptr(order), cap, C.byref(n)))
+        xyr, order = xyr[:n.value], order[:n.value]
+        o = np.argsort(order, kind="stable")
+        return xyr[o].copy(), order[o].copy()
+
+    def debug_level_keypoints(self, level: int, frame: int = 0):
+        cap = self.max_keypoints
+        xyr = np.zeros((cap, 3), np.float32)
+        n = C.c_int()
+        check(self._L.orbx_debug_level_keypoints(self._h, frame, level, ptr(xyr), cap, C.byref(n)))
+        return xyr[:n.value].copy()
+
+
+def keypoints_from_device(kps_u8, counts, frame: int) -> np.ndarray:
+    """Host KP_DTYPE view of frame `frame` of the tensors returned by extract_batch_device."""
+    n = int(counts[frame, 0])
+    raw = kps_u8[frame, :n].cpu().numpy()
+    return np.frombuffer(raw.tobytes(), dtype=KP_DTYPE)
