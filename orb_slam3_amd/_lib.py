@@ -87,6 +87,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C orb_slam3_amd/csrc` "
                               "(there is no CPU fallback)")
+        # One HIP runtime per process: PyTorch's ROCm wheel bundles its own libamdhip64 (same
+        # SONAME as the system one).  Importing torch first makes the dynamic loader resolve
+        # liborbx.so's dependency to that already-loaded runtime, so device pointers and
+        # streams can be shared with torch tensors.  Without torch the system runtime is used.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)   # raises AttributeError on a missing export

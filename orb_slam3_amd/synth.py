@@ -92,6 +92,8 @@ def stereo_pair(w: int, h: int, seed: int, n_prims: int = 400, noise_sigma: floa
     rng = np.random.default_rng(seed)
     bg = 60.0 + _value_noise(rng, w + 8, h)
     prims = _primitives(rng, w, h, n_prims)
+    order = np.argsort(prims[6], kind="stable")      # far (small disparity) first: consistent occlusion
+    prims = tuple(p[order] for p in prims)
     left = bg[:, 0:w].copy()
     right = bg[:, 3:w + 3].copy()
     _draw(left, prims, 0)

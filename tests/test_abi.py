@@ -1,0 +1,73 @@
+"""The C ABI library loads without a GPU and exports every symbol include/orbx.h declares;
+entry points that need a device fail with a status, never crash."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "orbx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = set(re.findall(r"\b(orbx_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
+
+
+def test_header_and_prototypes_agree():
+    from orb_slam3_amd import _lib
+    assert set(_declared()) == set(_lib.PROTOTYPES.keys())
+
+
+def test_library_exports_every_declared_symbol():
+    from orb_slam3_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "liborbx.so not built (make -C orb_slam3_amd/csrc)"
+    L = C.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(L, name), f"missing export {name}"
+    _lib.lib()   # prototypes attach
+
+
+def test_struct_layouts():
+    from orb_slam3_amd import _lib
+    assert _lib.KP_DTYPE.itemsize == 28          # cv::KeyPoint
+    assert _lib.MATCH2_DTYPE.itemsize == 16
+    assert _lib.QUERY_DTYPE.itemsize == 24
+    assert _lib.RECT_DTYPE.itemsize == 16
+    assert C.sizeof(_lib.OrbxParams) == 36
+
+
+def test_no_cpu_fallback_in_product_package():
+    # the product package must not import or call the oracle
+    pkg = os.path.join(ROOT, "orb_slam3_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt.lower().replace("no cpu fallback", ""), f"{f} mentions the oracle"
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from orb_slam3_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        _lib.lib()
+
+
+def test_argument_validation_without_device():
+    # invalid arguments are rejected before any device work
+    from orb_slam3_amd import _lib
+    L = _lib.lib()
+    h = C.c_void_p()
+    p = _lib.OrbxParams(1000, 1.2, 99, 20, 7, 752, 480, 1, -1)
+    assert L.orbx_extractor_create(C.byref(p), C.byref(h)) == _lib.ORBX_ERR_INVALID
+    assert b"nlevels" in L.orbx_last_error()
+    p = _lib.OrbxParams(0, 1.2, 8, 20, 7, 752, 480, 1, -1)
+    assert L.orbx_extractor_create(C.byref(p), C.byref(h)) == _lib.ORBX_ERR_INVALID
+    out = np.zeros(4, np.int32)
+    assert L.orbx_hamming_knn2(None, -1, None, 0, None) == _lib.ORBX_ERR_INVALID
+    assert L.orbx_descriptor_distance(None, None, 0, None) == _lib.ORBX_OK

@@ -1,0 +1,204 @@
+"""GPU parity of the HIP extractor against the CPU oracle, through the C ABI.
+Bit-exact bar: keypoint coordinates, octaves, sizes, responses, angles, descriptors, output
+order and monoIndex must all be identical (angles are compared exactly; north-star tolerance
+would be 1e-3 rad)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from orb_slam3_amd import synth
+
+
+def _gpu():
+    import orb_slam3_amd as A
+    assert A.lib().orbx_device_count() >= 1, "no HIP device: the GPU tests need an MI355X"
+    return A
+
+
+def _same(ka, da, ma, kb, db, mb):
+    assert ma == mb
+    assert len(ka) == len(kb)
+    for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(ka[f], kb[f]), f
+    assert np.array_equal(da, db)
+
+
+@pytest.mark.parametrize("w,h,nf,nl,seed,lap", [
+    (752, 480, 1000, 8, 1, (0, 1000)),      # EuRoC mono (Frame.cc:389)
+    (752, 480, 1200, 8, 2, (0, 0)),         # EuRoC stereo
+    (1241, 376, 2000, 8, 3, (0, 0)),        # KITTI
+    (512, 512, 1000, 8, 4, (0, 511)),       # TUM-VI fisheye overlap
+    (600, 350, 1000, 8, 5, (0, 1000)),      # the fork's resized EuRoC
+    (641, 479, 700, 8, 6, (100, 300)),      # odd sizes, partial lapping
+    (200, 160, 300, 4, 7, (50, 120)),       # few levels
+    (320, 256, 50, 8, 8, (0, 0)),           # tiny quota: first sweep overshoots N
+    (752, 480, 5000, 8, 9, (0, 0)),         # mono initialisation extractor (5 x nFeatures)
+])
+def test_extract_matches_oracle(oracle, w, h, nf, nl, seed, lap):
+    A = _gpu()
+    img = synth.scene(w, h, seed)
+    o = oracle.Extractor(nf, 1.2, nl, 20, 7)
+    g = A.ORBextractor(nf, 1.2, nl, 20, 7, max_width=w, max_height=h)
+    assert np.array_equal(g.mvScaleFactor, o.scale_factors)
+    assert np.array_equal(g.mvInvScaleFactor, o.inv_scale_factors)
+    assert np.array_equal(g.mvLevelSigma2, o.level_sigma2)
+    assert np.array_equal(g.mvInvLevelSigma2, o.inv_level_sigma2)
+    assert np.array_equal(g.mnFeaturesPerLevel, o.features_per_level)
+    ko, do, mo = o(img, lap)
+    kg, dg, mg = g(img, lap)
+    _same(ko, do, mo, kg, dg, mg)
+    for l in range(nl):
+        assert np.array_equal(o.pyramid_level(l), g.pyramid_level(l)), f"pyramid level {l}"
+        co = o.level_candidates(l)
+        cg, _ = g.debug_level_candidates(l)
+        assert np.array_equal(co, cg), f"FAST candidates level {l}"
+        lo, lg = o.level_keypoints(l), g.debug_level_keypoints(l)
+        assert np.array_equal(np.stack([lo["x"], lo["y"], lo["response"]], 1), lg), f"quadtree level {l}"
+    g.close()
+
+
+@pytest.mark.parametrize("ini,mn", [(20, 7), (12, 7), (40, 5), (7, 7), (5, 20)])
+def test_thresholds(oracle, ini, mn):
+    A = _gpu()
+    img = synth.scene(640, 480, 21, n_prims=120, noise_sigma=1.0)
+    o = oracle.Extractor(800, 1.2, 8, ini, mn)
+    g = A.ORBextractor(800, 1.2, 8, ini, mn, max_width=640, max_height=480)
+    _same(*o(img, (0, 0)), *g(img, (0, 0)))
+
+
+def test_low_texture_and_flat_images(oracle):
+    A = _gpu()
+    g = A.ORBextractor(500, 1.2, 8, 20, 7, max_width=640, max_height=480)
+    o = oracle.Extractor(500)
+    flat = np.full((480, 640), 77, np.uint8)
+    k, d, m = g(flat, (0, 0))
+    assert len(k) == 0 and m == 0
+    ko, do, mo = o(flat, (0, 0))
+    assert len(ko) == 0 and mo == 0
+    # a handful of corners only: quota never reached, cells fall back to the low threshold
+    sparse = flat.copy()
+    rng = np.random.default_rng(5)
+    for _ in range(12):
+        x, y = int(rng.integers(40, 600)), int(rng.integers(40, 440))
+        sparse[y:y + 9, x:x + 9] = 77 + int(rng.integers(8, 60))
+        sparse[y, x] += 30
+    _same(*o(sparse, (0, 0)), *g(sparse, (0, 0)))
+
+
+def test_scale_factor_and_levels_variants(oracle):
+    A = _gpu()
+    img = synth.scene(800, 600, 31)
+    for sf, nl in ((1.2, 8), (1.5, 4), (1.1, 6), (2.0, 3)):
+        o = oracle.Extractor(900, sf, nl, 20, 7)
+        g = A.ORBextractor(900, sf, nl, 20, 7, max_width=800, max_height=600)
+        _same(*o(img, (0, 0)), *g(img, (0, 0)))
+
+
+def test_dynamic_rects(oracle):
+    A = _gpu()
+    img = synth.scene(640, 480, 5)
+    rects = [(100, 80, 200, 160), (400, 300, 120, 100)]
+    o = oracle.Extractor(1000)
+    g = A.ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480)
+    g.mvDynamicArea = rects
+    ko, do, mo = o(img, (0, 0), rects)
+    _same(ko, do, mo, *g(img, (0, 0)))
+    g.mvDynamicArea = []
+    _same(*o(img, (0, 0)), *g(img, (0, 0)))
+
+
+def test_strided_input_and_size_change(oracle):
+    A = _gpu()
+    big = synth.scene(800, 600, 41)
+    view = big[20:500, 30:782]            # 752 x 480 window with a 800-byte row stride
+    assert view.strides[0] == 800
+    o = oracle.Extractor(1000)
+    g = A.ORBextractor(1000, 1.2, 8, 20, 7, max_width=800, max_height=600)
+    _same(*o(np.ascontiguousarray(view), (0, 0)), *g(view, (0, 0)))
+    _same(*o(big, (0, 0)), *g(big, (0, 0)))          # same handle, other size
+    small = np.ascontiguousarray(big[:300, :400])
+    _same(*o(small, (0, 0)), *g(small, (0, 0)))
+
+
+def test_empty_and_invalid(oracle):
+    A = _gpu()
+    g = A.ORBextractor(500, 1.2, 8, 20, 7, max_width=640, max_height=480)
+    k, d, m = g(np.zeros((0, 0), np.uint8))
+    assert m == -1 and len(k) == 0
+    with pytest.raises(A.OrbxError):
+        g(np.zeros((1000, 1000), np.uint8))       # larger than the handle
+    with pytest.raises(A.OrbxError):
+        g(np.zeros((100, 100), np.uint8))         # top level too small for the 35-px grid
+    with pytest.raises(A.OrbxError):
+        A.ORBextractor(500, 1.2, 40, 20, 7)
+
+
+def test_golden_vectors(golden_dir):
+    A = _gpu()
+    for f in sorted(glob.glob(os.path.join(golden_dir, "extract_*.npz"))):
+        gld = np.load(f)
+        w, h = int(gld["width"]), int(gld["height"])
+        img = synth.scene(w, h, int(gld["seed"]))
+        assert synth.checksum(img) == int(gld["image_crc"])
+        p = gld["params"]
+        g = A.ORBextractor(int(p[0]), float(p[1]), int(p[2]), int(p[3]), int(p[4]), max_width=w, max_height=h)
+        g.mvDynamicArea = [tuple(int(v) for v in r) for r in gld["rects"]]
+        k, d, m = g(img, tuple(int(v) for v in gld["lapping"]))
+        assert m == int(gld["mono_index"]), f
+        assert np.array_equal(k, gld["kps"]), f
+        assert np.array_equal(d, gld["desc"]), f
+
+
+def test_batch_equals_single_and_is_deterministic(oracle):
+    A = _gpu()
+    import torch
+    imgs = [synth.scene(752, 480, 100 + i) for i in range(6)]
+    g = A.ORBextractor(1000, 1.2, 8, 20, 7, max_width=752, max_height=480, max_batch=6)
+    single = [g(im, (0, 1000)) for im in imgs]
+    batch = g.extract_batch(imgs, (0, 1000))
+    for s, b in zip(single, batch):
+        _same(*s, *b)
+    o = oracle.Extractor(1000)
+    _same(*o(imgs[3], (0, 1000)), *batch[3])
+    # device-resident path, twice
+    d = torch.from_numpy(np.stack(imgs)).cuda()
+    outs = []
+    for _ in range(2):
+        kps, desc, counts = g.extract_batch_device(d, (0, 1000))
+        torch.cuda.synchronize()
+        g.status()
+        outs.append((kps.cpu().numpy().copy(), desc.cpu().numpy().copy(), counts.cpu().numpy().copy()))
+    c = outs[0][2]
+    for f in range(6):
+        n = c[f, 0]
+        assert n == len(single[f][0]) and c[f, 1] == single[f][2]
+        k = np.frombuffer(outs[0][0][f, :n].tobytes(), dtype=A.KP_DTYPE)
+        assert np.array_equal(k, single[f][0])
+        assert np.array_equal(outs[0][1][f, :n], single[f][1])
+        assert np.array_equal(outs[0][0][f, :n], outs[1][0][f, :n]) and np.array_equal(outs[0][1][f, :n], outs[1][1][f, :n])
+
+
+def test_full_hd_5000_features(oracle):
+    # BASELINE config 4 frame shape, one frame against the oracle
+    A = _gpu()
+    img = synth.scene(1920, 1080, 4, n_prims=1500)
+    o = oracle.Extractor(5000)
+    g = A.ORBextractor(5000, 1.2, 8, 20, 7, max_width=1920, max_height=1080)
+    ko, do, mo = o(img, (0, 0))
+    kg, dg, mg = g(img, (0, 0))
+    assert len(ko) >= 5000
+    _same(ko, do, mo, kg, dg, mg)
+
+
+def test_candidate_buffer_regrows(oracle):
+    # pure noise has far more FAST corners than the default candidate capacity
+    A = _gpu()
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    o = oracle.Extractor(1000)
+    g = A.ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480)
+    _same(*o(img, (0, 0)), *g(img, (0, 0)))

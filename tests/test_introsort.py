@@ -1,0 +1,70 @@
+"""The device-side restatement of libstdc++'s std::sort must produce the same permutation as
+std::sort itself for comparators with many ties (ORBextractor.cc:805 sorts nodes that tie)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SRC = textwrap.dedent(r'''
+    #include "orb_slam3_amd/csrc/orbx_introsort.h"
+    #include <algorithm>
+    #include <cstdio>
+    #include <random>
+    #include <vector>
+    typedef unsigned long long u64;
+    static bool cmp(const u64& a, const u64& b) { return orbx_sort::less(a, b); }
+    int main() {
+        std::mt19937_64 rng(7);
+        long bad = 0, cases = 0;
+        int stack[3 * orbx_sort::kStackDepth];
+        for (int n = 0; n <= 2600; n += (n < 70 ? 1 : 31)) {
+            for (int mode = 0; mode < 8; ++mode) {
+                std::vector<u64> a(n);
+                for (int i = 0; i < n; ++i) {
+                    uint32_t cnt, ulx;
+                    switch (mode) {
+                        case 0: cnt = 2 + rng() % 2; ulx = 16 * (rng() % 4); break;      // heavy ties
+                        case 1: cnt = 2 + rng() % 6; ulx = rng() % 40; break;
+                        case 2: cnt = 2 + rng() % 50; ulx = rng() % 700; break;
+                        case 3: cnt = rng() % 100000; ulx = rng() % 30000; break;         // large counts
+                        case 4: cnt = i; ulx = 0; break;                                  // sorted
+                        case 5: cnt = n - i; ulx = 0; break;                              // reversed
+                        case 6: cnt = (i < n / 2) ? i : (n - i); ulx = 3; break;          // organ pipe
+                        default: cnt = (i % 2) ? i : 0; ulx = i % 3; break;
+                    }
+                    a[i] = orbx_sort::make_elem(cnt, ulx, (uint32_t)i);
+                }
+                std::vector<u64> b = a;
+                std::sort(a.begin(), a.end(), cmp);
+                orbx_sort::sort(b.data(), n, stack);
+                ++cases;
+                if (a != b) { ++bad; if (bad < 5) printf("MISMATCH n=%d mode=%d\n", n, mode); }
+            }
+        }
+        // heapsort fallback (taken when the quicksort depth limit is exhausted)
+        for (int n = 2; n < 400; ++n) {
+            std::vector<u64> a(n);
+            for (int i = 0; i < n; ++i) a[i] = orbx_sort::make_elem(rng() % 5, rng() % 3, i);
+            std::vector<u64> b = a;
+            std::partial_sort(a.begin(), a.end(), a.end(), cmp);
+            orbx_sort::heap_sort(b.data(), 0, n);
+            ++cases;
+            if (a != b) { ++bad; printf("HEAP MISMATCH n=%d\n", n); }
+        }
+        printf("cases=%ld bad=%ld\n", cases, bad);
+        return bad ? 1 : 0;
+    }
+''')
+
+
+def test_introsort_matches_libstdcxx(tmp_path):
+    src = tmp_path / "t.cpp"
+    src.write_text(SRC)
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", ROOT, str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    sys.stdout.write(out.stdout)
+    assert out.returncode == 0, out.stdout
+    assert "bad=0" in out.stdout
