@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Benchmark of the ORB front-end hot path on MI355X.
+
+A step = one pass of the hot path over one batch of synthetic EuRoC-shaped stereo pairs that
+are already resident in HBM: left + right ORBextractor::operator() (752x480, 1000 features,
+8 levels x 1.2, FAST 20/7) followed by Frame::ComputeStereoMatches -- BASELINE.json configs[1].
+value = ORB frames (images) extracted per second, summed over all ranks.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): frames are sharded over the ranks,
+no data-path collective (weak scaling); the timing is barrier-bracketed and the max over ranks.
+The Hamming half of the metric is reported in the same line under "hamming": 5000 query
+descriptors against a 10 M descriptor map sharded in contiguous ranges over the ranks, local
+top-2 per rank, one RCCL all-gather of the 80 KB partial results, lexicographic merge.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (per-cell FAST): algorithmic bytes / hipEvent-timed duration
+  path_roofline whole step: compulsory bytes per frame (input + pyramid + results) / step time
+  cpu_baseline  the CPU oracle (a plain port of the reference path) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, NFEAT, NLEVELS, SCALE, INI_TH, MIN_TH = 752, 480, 1000, 8, 1.2, 20, 7
+MBF, FX = 47.90639384423901, 435.2046959714599          # EuRoC-like baseline * fx and fx
+HBM_PEAK_GBS = 8000.0                                     # MI355X HBM3E spec
+VALU_U32_PEAK = 256 * 4 * 32 * 2.4e9                      # lane-ops/s (256 CU x 4 SIMD x 32 lanes x 2.4 GHz)
+NQ_MAP, NT_MAP = 5000, 10_000_000
+
+
+def level_pixels(ex):
+    import ctypes as C
+    tot = 0
+    for l in range(NLEVELS):
+        w, h = C.c_int(), C.c_int()
+        ex._L.orbx_pyramid_level(ex.handle, 0, l, None, 0, C.byref(w), C.byref(h))
+        tot += w.value * h.value
+    return tot
+
+
+def cpu_baseline(n_pairs):
+    """The CPU oracle (single thread, a plain port of the reference path) on n_pairs stereo pairs."""
+    from oracle import oracle as O
+    from orb_slam3_amd import synth
+    pairs = [synth.stereo_pair(W, H, 9000 + i) for i in range(n_pairs)]
+    eL = O.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
+    eR = O.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
+    t0 = time.perf_counter()
+    t_ext = 0.0
+    for L, R in pairs:
+        a = time.perf_counter()
+        kL, dL, _ = eL(L, (0, 0))
+        kR, dR, _ = eR(R, (0, 0))
+        t_ext += time.perf_counter() - a
+        pl = [eL.pyramid_level(l) for l in range(NLEVELS)]
+        pr = [eR.pyramid_level(l) for l in range(NLEVELS)]
+        O.stereo_match(kL, dL, kR, dR, pl, pr, eL.scale_factors, eL.inv_scale_factors, MBF, MBF / FX)
+    dt = time.perf_counter() - t0
+    # brute-force matcher sample (hardware popcount variant = the faster CPU form)
+    q = synth.random_descriptors(64, 5)
+    t = synth.random_descriptors(500_000, 6)
+    a = time.perf_counter()
+    O.knn2(q, t, True)
+    t_knn = time.perf_counter() - a
+    return {"value": 2 * n_pairs / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n_pairs} synthetic 752x480 stereo pairs, CPU oracle: 2 extractions + stereo match per pair",
+            "extract_ms_per_frame": 1e3 * t_ext / (2 * n_pairs),
+            "hamming_pairs_per_s": 64 * 500_000 / t_knn}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="stereo pairs per step per GPU")
+    ap.add_argument("--cpu-pairs", type=int, default=16, help="stereo pairs of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-hamming", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import orb_slam3_amd as A
+    from orb_slam3_amd import synth
+
+    B = args.batch
+    # distinct frames per rank (seeded); a handful of distinct scenes tiled over the batch
+    n_unique = min(B, 8)
+    pairs = [synth.stereo_pair(W, H, 1000 * (rank + 1) + i) for i in range(n_unique)]
+    left = np.stack([pairs[i % n_unique][0] for i in range(B)])
+    right = np.stack([pairs[i % n_unique][1] for i in range(B)])
+    dL = torch.from_numpy(left).to(dev)
+    dR = torch.from_numpy(right).to(dev)
+    exL = A.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local)
+    exR = A.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local)
+    cap = exL.max_keypoints
+    mk = lambda: (torch.empty((B, cap, 28), dtype=torch.uint8, device=dev),
+                  torch.empty((B, cap, 32), dtype=torch.uint8, device=dev),
+                  torch.empty((B, 2), dtype=torch.int32, device=dev))
+    outL, outR = mk(), mk()
+
+    # left and right extraction run on two HIP streams (the reference runs them on two
+    # threads, Frame.cc:143-147); the stereo matcher waits for both
+    sL, sR = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+
+    def step():
+        cur = torch.cuda.current_stream(dev)
+        sL.wait_stream(cur); sR.wait_stream(cur)
+        with torch.cuda.stream(sL):
+            exL.extract_batch_device(dL, (0, 0), out=outL)
+        with torch.cuda.stream(sR):
+            exR.extract_batch_device(dR, (0, 0), out=outR)
+        sL.wait_stream(sR)
+        with torch.cuda.stream(sL):
+            r = A.compute_stereo_matches_device(exL, exR, outL, outR, MBF, MBF / FX)
+        cur.wait_stream(sL)
+        return r
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(max(args.warmup, 1)):
+        ur, depth = step()
+        torch.cuda.synchronize()
+        exL.status(); exR.status()        # a capacity overflow regrows the buffers during warm-up
+    exL.set_timing(True); exR.set_timing(True)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ur, depth = step()
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    exL.status(); exR.status()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tL, nL = exL.get_timing()
+    tR, nR = exR.get_timing()
+    exL.set_timing(False); exR.set_timing(False)
+    frames_per_step = 2 * B * world
+    value = frames_per_step * args.steps / dt
+    counts = outL[2].cpu().numpy()
+    n_kp = float(counts[:, 0].mean())
+    n_match = float((ur[0, :int(counts[0, 0])] >= 0).sum().item())
+
+    # --- roofline of the dominant kernel (FAST cells): pixels of every level read once + candidates written
+    px = level_pixels(exL)
+    stage_ms = {k: (tL[k] + tR[k]) / max(nL + nR, 1) for k in tL}       # per launch (B frames)
+    dominant = max(stage_ms, key=stage_ms.get)
+    n_cand = 0
+    for l in range(NLEVELS):
+        n_cand += len(exL.debug_level_candidates(l, 0)[0])
+    fast_bytes = B * (px + 16 * n_cand)
+    fast_s = stage_ms["fast"] * 1e-3
+    achieved = fast_bytes / fast_s / 1e9 if fast_s > 0 else 0.0
+    frame_bytes = W * H + px + 60 * n_kp                                   # input + pyramid + keypoints/descriptors
+    path_achieved = value / world * frame_bytes / 1e9
+
+    out = {
+        "metric": "ORB frames/sec (752x480, 1000 feat, 8 lvl) + Hamming matches/sec, 1-8 GPU",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "EuRoC stereo_euroc (BASELINE configs[1]): left+right extraction + "
+                               "ComputeStereoMatches, 752x480, nFeatures=1000, 8 levels x1.2, FAST 20/7",
+                   "pairs_per_step_per_gpu": B, "frames_per_step": frames_per_step,
+                   "keypoints_per_frame": n_kp, "stereo_matches_frame0": n_match, "parallelism": f"frames sharded x{world}"},
+        "roofline": {"bound": "hbm", "kernel": "k_fast", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": fast_bytes, "avg_launch_ms": stage_ms["fast"],
+                     "dominant_stage": dominant},
+        "path_roofline": {"bound": "hbm", "bytes_per_frame": frame_bytes, "achieved": path_achieved, "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": path_achieved / HBM_PEAK_GBS},
+        "stage_ms_per_launch": stage_ms,
+    }
+
+    # --- Hamming matches/s: 5000 queries vs 10 M map descriptors, sharded over the ranks
+    if not args.no_hamming:
+        g = torch.Generator(device=dev); g.manual_seed(5)
+        dq = torch.randint(0, 256, (NQ_MAP, 32), dtype=torch.uint8, device=dev, generator=g)
+        shard = NT_MAP // world
+        base = rank * shard
+        n_local = shard if rank < world - 1 else NT_MAP - base
+        g2 = torch.Generator(device=dev); g2.manual_seed(600 + rank)
+        dt_map = torch.randint(0, 256, (n_local, 32), dtype=torch.uint8, device=dev, generator=g2)
+        part = torch.empty((NQ_MAP, 4), dtype=torch.int32, device=dev)
+        gathered = torch.empty((world, NQ_MAP, 4), dtype=torch.int32, device=dev)
+        ws = None
+
+        def search():
+            nonlocal ws
+            p, ws = A.knn_match2_device(dq, dt_map, base_index=base, out=part, workspace=ws)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, p)
+                return A.knn2_merge_device(gathered)
+            return p
+        search(); torch.cuda.synchronize(); barrier()
+        iters = 5
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(iters):
+            res = search()
+        ev1.record()
+        torch.cuda.synchronize(); barrier()
+        th = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([th], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            th = float(t.item())
+        per = th / iters
+        pairs_s = NQ_MAP * NT_MAP / per
+        out["hamming"] = {"workload": f"{NQ_MAP} queries x {NT_MAP} map descriptors (BASELINE configs[4]), "
+                                      f"map sharded x{world}, top-2 all-gather + merge",
+                          "matches_per_s": NQ_MAP / per, "pairs_per_s": pairs_s, "ms_per_search": 1e3 * per,
+                          "scaling": "strong",
+                          "roofline": {"bound": "valu-u32", "ops_per_pair": 16, "achieved": pairs_s * 16 / 1e12,
+                                       "peak": VALU_U32_PEAK * world / 1e12, "unit": "Tops/s",
+                                       "frac": pairs_s * 16 / (VALU_U32_PEAK * world)}}
+
+    if rank == 0 and world == 1 and args.cpu_pairs > 0:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

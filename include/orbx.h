@@ -15,8 +15,10 @@
  *  - every function returns an orbx_status (0 = OK, negative = error) unless noted;
  *    orbx_last_error() gives the message of the calling thread's last failure;
  *  - "host" entry points take host pointers and are synchronous; "_device" entry points
- *    take device pointers, enqueue on the given hipStream_t (passed as void*; NULL = the
- *    handle's own stream) and do not synchronise;
+ *    take device pointers, enqueue on the given hipStream_t (passed as void* and taken
+ *    literally: NULL is the device's default stream) and do not synchronise; work that
+ *    consumes the results of two handles (stereo matching) must be ordered after both by
+ *    the caller (same stream, or an event wait);
  *  - one handle may be used by one thread at a time; distinct handles are independent
  *    (the reference runs one extractor per camera thread, Frame.cc:143-147);
  *  - orbx_keypoint has the memory layout of cv::KeyPoint (28 bytes) and descriptors are
@@ -134,6 +136,13 @@ orbx_status orbx_pyramid_level(orbx_extractor* ex, int frame, int level, uint8_t
 /* Device view of the same level: pointer and row pitch in bytes. */
 orbx_status orbx_pyramid_level_device(orbx_extractor* ex, int frame, int level, const uint8_t** d_ptr,
                                       int* width, int* height, ptrdiff_t* pitch);
+
+/* Per-kernel timing of the extractor with hipEvents recorded on the launch stream.
+ * set_timing(1) starts (and clears) the accumulation, get_timing() synchronises on the last
+ * recorded event and returns, summed over n_calls batches, the milliseconds of the 6 stages
+ * { copy-in, pyramid (all resize launches), FAST cells, quadtree, layout, describe }. */
+orbx_status orbx_extractor_set_timing(orbx_extractor* ex, int enable);
+orbx_status orbx_extractor_get_timing(orbx_extractor* ex, double* stage_ms, int n_stages, long* n_calls);
 
 /* Stage taps for tests (device results copied to the host, last call, batch slot `frame`):
  * FAST candidates of one level after the per-cell round trip, as rows of

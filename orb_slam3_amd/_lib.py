@@ -50,6 +50,8 @@ PROTOTYPES = {
                                             C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_void_p, C.c_void_p]),
     "orbx_extract_status": (C.c_int, [C.c_void_p]),
+    "orbx_extractor_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "orbx_extractor_get_timing": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_long)]),
     "orbx_pyramid_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
                                      C.POINTER(C.c_int)]),
     "orbx_pyramid_level_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int),

@@ -824,7 +824,42 @@ struct orbx_extractor {
     int outCap = 0;
     int lastFrames = 0;
     void* d_scratch = nullptr;     size_t scratchAlloc = 0;
+    // optional per-kernel timing (hipEvents on the launch stream)
+    bool timing = false;
+    std::vector<hipEvent_t> evPool;          // kTimedStages + 1 events per recorded batch
+    size_t evUsed = 0;
+    double stageMs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long stageCalls = 0;
 };
+constexpr int kTimedStages = 6;   // copy-in, pyramid, fast, quadtree, layout, describe
+static hipEvent_t next_event(orbx_extractor* ex) {
+    if (ex->evUsed == ex->evPool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        ex->evPool.push_back(e);
+    }
+    return ex->evPool[ex->evUsed++];
+}
+static void mark(orbx_extractor* ex, hipStream_t st) {
+    if (!ex->timing) return;
+    hipEvent_t e = next_event(ex);
+    if (e) hipEventRecord(e, st);
+}
+// Folds the recorded events into stageMs (synchronises on the last event).
+static void resolve_timing(orbx_extractor* ex) {
+    const size_t per = kTimedStages + 1;
+    const size_t nb = ex->evUsed / per;
+    if (nb == 0) { ex->evUsed = 0; return; }
+    hipEventSynchronize(ex->evPool[nb * per - 1]);
+    for (size_t b = 0; b < nb; ++b) {
+        for (int s = 0; s < kTimedStages; ++s) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ex->evPool[b * per + s], ex->evPool[b * per + s + 1]) == hipSuccess) ex->stageMs[s] += ms;
+        }
+        ++ex->stageCalls;
+    }
+    ex->evUsed = 0;
+}
 
 static void host_linear_taps(int ssize, int dsize, int* ofs, short* coef) {
     // cv::resize's coefficient set-up for INTER_LINEAR, 8-bit: 11-bit fixed point
@@ -1006,6 +1041,7 @@ extern "C" void orbx_extractor_destroy(orbx_extractor* ex) {
     if (!ex) return;
     hipSetDevice(ex->device);
     if (ex->stream) { hipStreamSynchronize(ex->stream); hipStreamDestroy(ex->stream); }
+    for (hipEvent_t e : ex->evPool) hipEventDestroy(e);
     free_geo_buffers(ex);
     hipFree(ex->d_geo); hipFree(ex->d_candCount); hipFree(ex->d_kpCount); hipFree(ex->d_err);
     hipFree(ex->d_rects); hipFree(ex->d_scratch); hipFree(ex->d_outKps); hipFree(ex->d_outDesc); hipFree(ex->d_counts);
@@ -1049,20 +1085,27 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
     ORBX_HIP_TRY(hipMemsetAsync(ex->d_candCount, 0, (size_t)nf * nl * sizeof(int), st));
     ORBX_HIP_TRY(hipMemsetAsync(ex->d_kpCount, 0, (size_t)nf * nl * sizeof(int), st));
     ORBX_HIP_TRY(hipMemsetAsync(ex->d_err, 0, sizeof(OrbxErr), st));
+    if (ex->timing && ex->evUsed + kTimedStages + 1 > 4096 * (size_t)(kTimedStages + 1)) resolve_timing(ex);
+    mark(ex, st);   // end of copy-in (its start is marked by the caller)
     for (int l = 1; l < nl; ++l) {
         dim3 grid((g.lv[l].w + 4 * 256 - 1) / (4 * 256), g.lv[l].h, nf);
         hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, ex->d_geo, l, ex->d_pyr, g.pyrBytes, ex->d_xofs, ex->d_xcoef,
                            ex->d_yofs, ex->d_ycoef);
     }
+    mark(ex, st);
     hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nf), dim3(256), 0, st, ex->d_geo, ex->d_pyr, g.pyrBytes, ex->d_cands,
                        ex->d_candCount, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->d_rects, ndyn, ex->d_err);
+    mark(ex, st);
     const size_t qtLds = (size_t)g.maxNodeCap * 56 + kQtThreads * sizeof(int);
     hipLaunchKernelGGL(k_quadtree, dim3(nl, nf), dim3(kQtThreads), qtLds, st, ex->d_geo, ex->d_cands, ex->d_candCount,
                        ex->d_keyNode, ex->d_levelKps, ex->d_kpCount, ex->d_err);
+    mark(ex, st);
     hipLaunchKernelGGL(k_layout, dim3(nf), dim3(kLayThreads), 0, st, ex->d_geo, ex->d_levelKps, ex->d_kpCount, lap0, lap1,
                        capacity, d_counts, ex->d_err);
+    mark(ex, st);
     hipLaunchKernelGGL(k_describe, dim3((g.kpTotal + kDescWaves - 1) / kDescWaves, nf), dim3(64 * kDescWaves), 0, st,
                        ex->d_geo, ex->d_pyr, g.pyrBytes, ex->d_levelKps, ex->d_kpCount, d_kps, d_desc, capacity);
+    mark(ex, st);
     ORBX_HIP_TRY(hipMemcpyAsync(ex->h_err, ex->d_err, sizeof(OrbxErr), hipMemcpyDeviceToHost, st));
     ORBX_HIP_TRY(hipGetLastError());
     ex->lastFrames = nf;
@@ -1079,8 +1122,9 @@ extern "C" orbx_status orbx_extract_batch_device(orbx_extractor* ex, const uint8
     ORBX_HIP_TRY(hipSetDevice(ex->device));
     orbx_status s = ensure_geometry(ex, width, height);
     if (s != ORBX_OK) return s;
-    hipStream_t st = stream ? (hipStream_t)stream : ex->stream;
+    hipStream_t st = (hipStream_t)stream;   // taken literally: NULL is the device's default stream
     dim3 grid((width + 255) / 256, height, n_frames);
+    mark(ex, st);
     hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, st, ex->d_geo, d_images, (long long)row_stride,
                        (long long)frame_stride, ex->d_pyr, ex->geo.pyrBytes);
     return enqueue_batch(ex, n_frames, lap0, lap1, dyn_host, ndyn, d_keypoints, d_descriptors, capacity, d_counts, st);
@@ -1122,6 +1166,7 @@ extern "C" orbx_status orbx_extract_batch(orbx_extractor* ex, const uint8_t* con
     if (s != ORBX_OK) return s;
     const OrbxLevelGeo& L0 = ex->geo.lv[0];
     for (int attempt = 0; attempt < 8; ++attempt) {
+        mark(ex, ex->stream);
         for (int f = 0; f < n_frames; ++f) {
             if (!images[f]) { orbx_set_error("empty image"); return ORBX_ERR_EMPTY; }
             ORBX_HIP_TRY(hipMemcpy2DAsync(ex->d_pyr + (size_t)f * ex->geo.pyrBytes + L0.off, L0.pitch, images[f], stride,
@@ -1174,6 +1219,7 @@ extern "C" orbx_status orbx_extract(orbx_extractor* ex, const uint8_t* image, in
     if (s != ORBX_OK) return s;
     const OrbxLevelGeo& L0 = ex->geo.lv[0];
     for (int attempt = 0; attempt < 8; ++attempt) {
+        mark(ex, ex->stream);
         ORBX_HIP_TRY(hipMemcpy2DAsync(ex->d_pyr + L0.off, L0.pitch, image, stride, width, height, hipMemcpyHostToDevice,
                                       ex->stream));
         s = enqueue_batch(ex, 1, lap0, lap1, dyn, ndyn, ex->d_outKps, ex->d_outDesc, ex->outCap, ex->d_counts, ex->stream);
@@ -1193,6 +1239,26 @@ extern "C" orbx_status orbx_extract(orbx_extractor* ex, const uint8_t* image, in
         ORBX_HIP_TRY(hipMemcpy(keypoints, ex->d_outKps, counts[0] * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
         ORBX_HIP_TRY(hipMemcpy(descriptors, ex->d_outDesc, (size_t)counts[0] * 32, hipMemcpyDeviceToHost));
     }
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_extractor_set_timing(orbx_extractor* ex, int enable) {
+    ORBX_REQUIRE(ex, "null handle");
+    ORBX_HIP_TRY(hipSetDevice(ex->device));
+    if (ex->timing) resolve_timing(ex);
+    ex->timing = enable != 0;
+    for (double& v : ex->stageMs) v = 0;
+    ex->stageCalls = 0;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_extractor_get_timing(orbx_extractor* ex, double* stage_ms, int n_stages, long* n_calls) {
+    ORBX_REQUIRE(ex && stage_ms && n_calls, "null argument");
+    ORBX_REQUIRE(n_stages >= kTimedStages, "need room for %d stages", kTimedStages);
+    ORBX_HIP_TRY(hipSetDevice(ex->device));
+    resolve_timing(ex);
+    for (int s = 0; s < kTimedStages; ++s) stage_ms[s] = ex->stageMs[s];
+    *n_calls = ex->stageCalls;
     return ORBX_OK;
 }
 

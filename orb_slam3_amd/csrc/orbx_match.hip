@@ -411,7 +411,7 @@ extern "C" orbx_status orbx_stereo_match_batch_device(orbx_extractor* left, orbx
     ORBX_REQUIRE(capacity >= 1 && capacity < (1 << 20), "bad capacity");
     ORBX_REQUIRE(mb > 0.f, "baseline must be positive");
     ORBX_HIP_TRY(hipSetDevice(orbx_internal_device(left)));
-    hipStream_t st = stream ? (hipStream_t)stream : orbx_internal_stream(left);
+    hipStream_t st = (hipStream_t)stream;   // taken literally: NULL is the device's default stream
     OrbxPyrView pv;
     pv.left = orbx_internal_pyramid(left);
     pv.right = orbx_internal_pyramid(right);
@@ -451,7 +451,7 @@ extern "C" orbx_status orbx_stereo_match(orbx_extractor* left, orbx_extractor* r
     ORBX_HIP_TRY(hipMemcpy(cl.p, cL, 8, hipMemcpyHostToDevice));
     ORBX_HIP_TRY(hipMemcpy(cr.p, cR, 8, hipMemcpyHostToDevice));
     hipStream_t st = orbx_internal_stream(left);
-    ORBX_HIP_TRY(hipStreamSynchronize(orbx_internal_stream(right)));
+    ORBX_HIP_TRY(hipStreamSynchronize(orbx_internal_stream(right)));   // the right pyramid was built on its own stream
     orbx_status s = orbx_stereo_match_batch_device(left, right, 1, kl.as<orbx_keypoint>(), dl.as<uint8_t>(), cl.as<int>(),
                                                    kr.as<orbx_keypoint>(), dr.as<uint8_t>(), cr.as<int>(), cap, mbf, mb,
                                                    ur.as<float>(), dp.as<float>(), st);

@@ -134,6 +134,19 @@ class ORBextractor:
         """Raises if the last asynchronous batch overflowed an internal buffer."""
         check(self._L.orbx_extract_status(self._h))
 
+    STAGES = ("copy_in", "pyramid", "fast", "quadtree", "layout", "describe")
+
+    def set_timing(self, enable: bool):
+        check(self._L.orbx_extractor_set_timing(self._h, 1 if enable else 0))
+
+    def get_timing(self):
+        """Per-stage milliseconds summed over the batches since set_timing(True), and the
+        number of batches: ({stage: ms}, n_calls)."""
+        ms = np.zeros(8, np.float64)
+        n = C.c_long()
+        check(self._L.orbx_extractor_get_timing(self._h, ptr(ms), 8, C.byref(n)))
+        return dict(zip(self.STAGES, ms[:6].tolist())), n.value
+
     def pyramid_level(self, level: int, frame: int = 0) -> np.ndarray:
         """mvImagePyramid[level] of the last call (borderless copy)."""
         w, h = C.c_int(), C.c_int()
