@@ -63,6 +63,8 @@ struct OrbxFrameGeo {
     long long candTotal;     // one frame's candidate records
     int kpTotal;             // one frame's distributed keypoint records
     int maxNodeCap;
+    int tileP, tileR;        // LDS tile of the FAST kernel: pitch (bytes) and rows
+    int fastLds;             // its dynamic LDS size in bytes
     OrbxLevelGeo lv[kOrbxMaxLevels];
 };
 

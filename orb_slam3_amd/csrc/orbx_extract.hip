@@ -63,12 +63,20 @@ struct OrbxErr {
 };
 
 // ======================================================================================
-// k_resize: 8-bit bilinear resize in 11-bit fixed point, 4 output pixels per lane
+// k_resize: 8-bit bilinear resize in 11-bit fixed point, 4 output pixels per lane.
+// The source bytes a lane needs (two rows, <= 16 consecutive columns for scale factors up to
+// 3) are fetched as aligned dwords and picked apart in registers; the per-column taps come
+// as one int4 of source offsets and one uint4 of packed (a0 | a1 << 16) coefficients.
 // ======================================================================================
+__device__ __forceinline__ int pick_byte(unsigned long long lo, unsigned long long hi, int k) {
+    const unsigned long long v = (k < 8) ? lo : hi;
+    return (int)((v >> ((k & 7) * 8)) & 255ull);
+}
+
 __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__ geo, int level,
                                                 uint8_t* __restrict__ pyr, long long frameStride,
-                                                const int* __restrict__ xofs, const short* __restrict__ xcoef,
-                                                const int* __restrict__ yofs, const short* __restrict__ ycoef) {
+                                                const int* __restrict__ xofs, const uint32_t* __restrict__ xcoef,
+                                                const int* __restrict__ yofs, const uint32_t* __restrict__ ycoef) {
     const OrbxLevelGeo& S = geo->lv[level - 1];
     const OrbxLevelGeo& D = geo->lv[level];
     const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -78,35 +86,63 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__
     uint8_t* dst = pyr + (long long)blockIdx.z * frameStride + D.off;
     const int sy0 = yofs[D.tapY + y];
     const int sy1 = min(sy0 + 1, S.h - 1);
-    const int b0 = ycoef[2 * (D.tapY + y)], b1 = ycoef[2 * (D.tapY + y) + 1];
+    const uint32_t yc = ycoef[D.tapY + y];
+    const int b0 = (int)(yc & 0xFFFFu), b1 = (int)(yc >> 16);
     const uint8_t* r0 = src + (long long)sy0 * S.pitch;
     const uint8_t* r1 = src + (long long)sy1 * S.pitch;
+    const int4 o = *reinterpret_cast<const int4*>(xofs + D.tapX + x4);        // padded to a multiple of 4
+    const uint4 c = *reinterpret_cast<const uint4*>(xcoef + D.tapX + x4);
+    const int so[4] = {o.x, o.y, o.z, o.w};
+    const uint32_t co[4] = {c.x, c.y, c.z, c.w};
+    const int last = min(o.w + 1, S.w - 1);
+    const int base = o.x & ~3;
     uint32_t packed = 0;
+    if (last - base < 16) {
+        const uint32_t* p0 = reinterpret_cast<const uint32_t*>(r0 + base);
+        const uint32_t* p1 = reinterpret_cast<const uint32_t*>(r1 + base);
+        const unsigned long long lo0 = p0[0] | ((unsigned long long)p0[1] << 32), hi0 = p0[2] | ((unsigned long long)p0[3] << 32);
+        const unsigned long long lo1 = p1[0] | ((unsigned long long)p1[1] << 32), hi1 = p1[2] | ((unsigned long long)p1[3] << 32);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int x = min(x4 + i, D.w - 1);
-        const int sx0 = xofs[D.tapX + x];
-        const int sx1 = min(sx0 + 1, S.w - 1);
-        const int a0 = xcoef[2 * (D.tapX + x)], a1 = xcoef[2 * (D.tapX + x) + 1];
-        const int t0 = r0[sx0] * a0 + r0[sx1] * a1;
-        const int t1 = r1[sx0] * a0 + r1[sx1] * a1;
-        const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
-        packed |= (uint32_t)(v & 255) << (8 * i);
+        for (int i = 0; i < 4; ++i) {
+            const int k0 = so[i] - base, k1 = min(so[i] + 1, S.w - 1) - base;
+            const int a0 = (int)(co[i] & 0xFFFFu), a1 = (int)(co[i] >> 16);
+            const int t0 = pick_byte(lo0, hi0, k0) * a0 + pick_byte(lo0, hi0, k1) * a1;
+            const int t1 = pick_byte(lo1, hi1, k0) * a0 + pick_byte(lo1, hi1, k1) * a1;
+            const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 255) << (8 * i);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sx0 = so[i], sx1 = min(sx0 + 1, S.w - 1);
+            const int a0 = (int)(co[i] & 0xFFFFu), a1 = (int)(co[i] >> 16);
+            const int t0 = r0[sx0] * a0 + r0[sx1] * a1;
+            const int t1 = r1[sx0] * a0 + r1[sx1] * a1;
+            const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+            packed |= (uint32_t)(v & 255) << (8 * i);
+        }
     }
     *reinterpret_cast<uint32_t*>(dst + (long long)y * D.pitch + x4) = packed;   // pitch padding absorbs the tail
 }
 
-// Copies n_frames images (row_stride / frame_stride) into level 0 of each pyramid slab.
+// Copies n_frames images (row_stride / frame_stride) into level 0 of each pyramid slab,
+// 16 bytes per lane when the source is 16-byte aligned, bytes otherwise.
 __global__ __launch_bounds__(256) void k_copy_level0(const OrbxFrameGeo* __restrict__ geo,
                                                      const uint8_t* __restrict__ images, long long rowStride,
                                                      long long imgStride, uint8_t* __restrict__ pyr,
-                                                     long long frameStride) {
+                                                     long long frameStride, int aligned16) {
     const OrbxLevelGeo& D = geo->lv[0];
-    const int x = (blockIdx.x * blockDim.x + threadIdx.x);
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
     const int y = blockIdx.y;
     if (x >= D.w) return;
-    pyr[(long long)blockIdx.z * frameStride + D.off + (long long)y * D.pitch + x] =
-        images[(long long)blockIdx.z * imgStride + (long long)y * rowStride + x];
+    const uint8_t* src = images + (long long)blockIdx.z * imgStride + (long long)y * rowStride + x;
+    uint8_t* dst = pyr + (long long)blockIdx.z * frameStride + D.off + (long long)y * D.pitch + x;
+    if (aligned16 && x + 16 <= D.w) {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+    } else {
+        const int n = min(16, D.w - x);
+        for (int i = 0; i < n; ++i) dst[i] = src[i];
+    }
 }
 
 // ======================================================================================
@@ -114,29 +150,18 @@ __global__ __launch_bounds__(256) void k_copy_level0(const OrbxFrameGeo* __restr
 // (initial threshold, then the lower one if the cell stayed empty), followed by the
 // fork's repeated level<->image scale round trip of every emitted corner.
 // ======================================================================================
-constexpr int kTileP = 80;   // LDS tile pitch; a cell image is at most 75 x 75
-
-__device__ __forceinline__ int fast_strength_lds(const uint8_t* t, int x, int y) {
+// LDS tile geometry is fixed per handle: pitch P (multiple of 4, >= widest cell image + 3 for
+// the alignment shift) and R rows; both come from the level geometry (OrbxFrameGeo::tileP/R).
+__device__ __forceinline__ int fast_strength_lds(const uint8_t* t, int P, int x, int y) {
     // d[k] = centre - circle[k]; strength = max over the 16 arcs of nine of
     // max(min(d), -max(d)).  Sliding minima / maxima by doubling: 2, 4, 8, then 9.
-    const int v = t[y * kTileP + x];
+    const uint8_t* c = t + y * P + x;
+    const int v = c[0];
     int d[16];
-    d[0] = v - t[(y + 3) * kTileP + x];
-    d[1] = v - t[(y + 3) * kTileP + x + 1];
-    d[2] = v - t[(y + 2) * kTileP + x + 2];
-    d[3] = v - t[(y + 1) * kTileP + x + 3];
-    d[4] = v - t[y * kTileP + x + 3];
-    d[5] = v - t[(y - 1) * kTileP + x + 3];
-    d[6] = v - t[(y - 2) * kTileP + x + 2];
-    d[7] = v - t[(y - 3) * kTileP + x + 1];
-    d[8] = v - t[(y - 3) * kTileP + x];
-    d[9] = v - t[(y - 3) * kTileP + x - 1];
-    d[10] = v - t[(y - 2) * kTileP + x - 2];
-    d[11] = v - t[(y - 1) * kTileP + x - 3];
-    d[12] = v - t[y * kTileP + x - 3];
-    d[13] = v - t[(y + 1) * kTileP + x - 3];
-    d[14] = v - t[(y + 2) * kTileP + x - 2];
-    d[15] = v - t[(y + 3) * kTileP + x - 1];
+    d[0] = v - c[3 * P];          d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];   d[3] = v - c[P + 3];
+    d[4] = v - c[3];              d[5] = v - c[-P + 3];      d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];
+    d[8] = v - c[-3 * P];         d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-P - 3];
+    d[12] = v - c[-3];            d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
     int mn2[16], mx2[16], mn4[16], mx4[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
@@ -164,15 +189,23 @@ __device__ __forceinline__ bool in_any_rect(float X, float Y, const orbx_rect* r
     return false;
 }
 
-__global__ __launch_bounds__(256) void k_fast(const OrbxFrameGeo* __restrict__ geo, const uint8_t* __restrict__ pyr,
-                                              long long frameStride, OrbxCand* __restrict__ cands,
-                                              int* __restrict__ candCount, int iniTh, int minTh,
-                                              const orbx_rect* __restrict__ rects, int nrects,
-                                              OrbxErr* __restrict__ err) {
-    __shared__ uint8_t tile[kTileP * kTileP];
-    __shared__ uint8_t strength[kTileP * kTileP];
-    __shared__ int s_nIni, s_nMin;
-    __shared__ uint32_t s_listIni[1296], s_listMin[1296];   // <= ceil(69/2)^2 = 1225 survivors per cell
+constexpr int kFastThreads = 128;
+
+__global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __restrict__ geo, const uint8_t* __restrict__ pyr,
+                                                       long long frameStride, OrbxCand* __restrict__ cands,
+                                                       int* __restrict__ candCount, int iniTh, int minTh,
+                                                       const orbx_rect* __restrict__ rects, int nrects,
+                                                       OrbxErr* __restrict__ err) {
+    // Dynamic LDS: image tile [R][P] (stored from the 4-byte aligned column at or left of the
+    // cell so that rows are fetched with dword loads), strength tile [R][P], and the queue of
+    // pixels that survive the quick reject (one ushort per testable pixel).  After the
+    // strengths are known the image tile is reused for the per-pixel keep flags.
+    extern __shared__ __align__(16) unsigned char fast_smem[];
+    __shared__ int s_nQueue, s_nIni, s_nMin;
+    const int P = geo->tileP, R = geo->tileR;
+    uint8_t* tile = fast_smem;
+    uint8_t* strength = tile + P * R;
+    unsigned short* s_queue = reinterpret_cast<unsigned short*>(strength + P * R);
 
     const int frame = blockIdx.y;
     int level = 0;
@@ -187,53 +220,107 @@ __global__ __launch_bounds__(256) void k_fast(const OrbxFrameGeo* __restrict__ g
     const int x1 = min(x0 + G.wCell + 6, maxBX), y1 = min(y0 + G.hCell + 6, maxBY);
     const int tw = x1 - x0, th = y1 - y0;
     const int tid = threadIdx.x;
+    const int xa = x0 & ~3, ox = x0 - xa;
+    const int rowDwords = (x1 - xa + 3) >> 2;           // <= P / 4
 
-    if (tid == 0) { s_nIni = 0; s_nMin = 0; }
+    if (tid == 0) { s_nQueue = 0; s_nIni = 0; s_nMin = 0; }
     const uint8_t* img = pyr + (long long)frame * frameStride + G.off;
-    for (int i = tid; i < tw * th; i += 256) {
-        const int y = i / tw, x = i - y * tw;
-        tile[y * kTileP + x] = img[(long long)(y0 + y) * G.pitch + x0 + x];
-        strength[y * kTileP + x] = 0;
+    {
+        const float invRow = 1.0f / (float)rowDwords;
+        for (int i = tid; i < rowDwords * th; i += kFastThreads) {
+            const int y = (int)(((float)i + 0.5f) * invRow), xd = i - y * rowDwords;
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (long long)(y0 + y) * G.pitch + xa + 4 * xd);
+            *reinterpret_cast<uint32_t*>(tile + y * P + 4 * xd) = v;
+            *reinterpret_cast<uint32_t*>(strength + y * P + 4 * xd) = 0u;
+        }
     }
     __syncthreads();
 
     const int iw = tw - 6, ih = th - 6;   // pixels FAST can test
     const int lowTh = min(iniTh, minTh);
+    uint8_t* T = tile + ox;               // T[y * P + x], x in cell coordinates
+    uint8_t* S = strength + ox;
     if (iw > 0 && ih > 0) {
-        for (int i = tid; i < iw * ih; i += 256) {
-            const int y = 3 + i / iw, x = 3 + i % iw;
-            const int s = fast_strength_lds(tile, x, y);
-            strength[y * kTileP + x] = (uint8_t)(s > lowTh ? s : 0);
+        // (A) quick reject: an arc of 9 contiguous circle pixels contains one pixel of every
+        // antipodal pair, so all four pairs {0,8} {4,12} {2,10} {6,14} need a member beyond the
+        // (lower) threshold on the same side.  Survivors are queued densely.
+        const float invW = 1.0f / (float)iw;
+        const int total = iw * ih;
+        for (int i0 = 0; i0 < total; i0 += kFastThreads) {
+            const int i = i0 + tid;
+            bool pass = false;
+            int x = 0, y = 0;
+            if (i < total) {
+                y = (int)(((float)i + 0.5f) * invW);
+                x = i - y * iw + 3;
+                y += 3;
+                const uint8_t* c = T + y * P + x;
+                const int v = c[0];
+                const int hi = v + lowTh, lo = v - lowTh;
+                const int p0 = c[3 * P], p8 = c[-3 * P], p4 = c[3], p12 = c[-3];
+                bool dark = (p0 < lo || p8 < lo) && (p4 < lo || p12 < lo);
+                bool bright = (p0 > hi || p8 > hi) && (p4 > hi || p12 > hi);
+                if (dark || bright) {
+                    const int p2 = c[2 * P + 2], p10 = c[-2 * P - 2], p6 = c[-2 * P + 2], p14 = c[2 * P - 2];
+                    dark = dark && (p2 < lo || p10 < lo) && (p6 < lo || p14 < lo);
+                    bright = bright && (p2 > hi || p10 > hi) && (p6 > hi || p14 > hi);
+                    pass = dark || bright;
+                }
+            }
+            const unsigned long long bal = __ballot(pass);
+            if (bal) {
+                const int lane = tid & 63;
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_nQueue, __popcll(bal));
+                base = __shfl(base, 0);
+                if (pass) s_queue[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(x | (y << 7));
+            }
         }
     }
     __syncthreads();
-    if (iw > 0 && ih > 0) {
-        for (int i = tid; i < iw * ih; i += 256) {
-            const int y = 3 + i / iw, x = 3 + i % iw;
-            const int s = strength[y * kTileP + x];
-            if (s == 0) continue;
+    const int nQueue = s_nQueue;
+    // (B) arc strength of the survivors
+    for (int q = tid; q < nQueue; q += kFastThreads) {
+        const int rec = s_queue[q];
+        const int x = rec & 127, y = rec >> 7;
+        const int st = fast_strength_lds(T, P, x, y);
+        S[y * P + x] = (uint8_t)(st > lowTh ? st : 0);
+    }
+    __syncthreads();
+    // (C) 3x3 non-maximum suppression at both thresholds; the verdicts go where the image was
+    for (int q = tid; q < nQueue; q += kFastThreads) {
+        const int rec = s_queue[q];
+        const int x = rec & 127, y = rec >> 7;
+        const int st = S[y * P + x];
+        int flags = 0;
+        if (st != 0) {
             int nb[8];
-            nb[0] = strength[(y - 1) * kTileP + x - 1]; nb[1] = strength[(y - 1) * kTileP + x];
-            nb[2] = strength[(y - 1) * kTileP + x + 1]; nb[3] = strength[y * kTileP + x - 1];
-            nb[4] = strength[y * kTileP + x + 1];       nb[5] = strength[(y + 1) * kTileP + x - 1];
-            nb[6] = strength[(y + 1) * kTileP + x];     nb[7] = strength[(y + 1) * kTileP + x + 1];
-            const int sI = score_at(s, iniTh), sM = score_at(s, minTh);
-            bool keepI = s > iniTh, keepM = s > minTh;
+            nb[0] = S[(y - 1) * P + x - 1]; nb[1] = S[(y - 1) * P + x];
+            nb[2] = S[(y - 1) * P + x + 1]; nb[3] = S[y * P + x - 1];
+            nb[4] = S[y * P + x + 1];       nb[5] = S[(y + 1) * P + x - 1];
+            nb[6] = S[(y + 1) * P + x];     nb[7] = S[(y + 1) * P + x + 1];
+            const int sI = score_at(st, iniTh), sM = score_at(st, minTh);
+            bool keepI = st > iniTh, keepM = st > minTh;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 keepI = keepI && (sI > score_at(nb[k], iniTh));
                 keepM = keepM && (sM > score_at(nb[k], minTh));
             }
-            const uint32_t rec = (uint32_t)x | ((uint32_t)y << 7);
-            if (keepI) s_listIni[atomicAdd(&s_nIni, 1)] = rec | ((uint32_t)sI << 14);
-            if (keepM) s_listMin[atomicAdd(&s_nMin, 1)] = rec | ((uint32_t)sM << 14);
+            flags = (keepI ? 1 : 0) | (keepM ? 2 : 0);
+        }
+        T[y * P + x] = (uint8_t)flags;
+        const unsigned long long bI = __ballot(flags & 1), bM = __ballot(flags & 2);
+        if ((tid & 63) == 0) {
+            if (bI) atomicAdd(&s_nIni, __popcll(bI));
+            if (bM) atomicAdd(&s_nMin, __popcll(bM));
         }
     }
     __syncthreads();
     const bool useIni = s_nIni > 0;
     const int n = useIni ? s_nIni : s_nMin;
-    const uint32_t* list = useIni ? s_listIni : s_listMin;
     if (n == 0) return;
+    const int wantFlag = useIni ? 1 : 2;
+    const int useTh = useIni ? iniTh : minTh;
 
     // Round trip: every corner found in the c-th processed cell is scaled to level 0 and
     // back once for each cell processed from its own to the last one of the level.
@@ -242,9 +329,11 @@ __global__ __launch_bounds__(256) void k_fast(const OrbxFrameGeo* __restrict__ g
     const float border = (float)kOrbxMinBorder;
     OrbxCand* out = cands + (long long)frame * geo->candTotal + G.candOff;
     int* counter = candCount + frame * nl + level;
-    for (int i = tid; i < n; i += 256) {
-        const uint32_t rec = list[i];
-        const int lx = rec & 127, ly = (rec >> 7) & 127, sc = rec >> 14;
+    for (int q = tid; q < nQueue; q += kFastThreads) {
+        const int rec = s_queue[q];
+        const int lx = rec & 127, ly = rec >> 7;
+        if (!(T[ly * P + lx] & wantFlag)) continue;
+        const int sc = score_at(S[ly * P + lx], useTh);
         float x = __fadd_rn((float)lx, (float)(cj * G.wCell));
         float y = __fadd_rn((float)ly, (float)(ci * G.hCell));
         bool erased = false;
@@ -609,7 +698,7 @@ __global__ __launch_bounds__(kLayThreads) void k_layout(const OrbxFrameGeo* __re
 //   256 steered comparisons -> 32 bytes
 // ======================================================================================
 constexpr int kDescWaves = 4;
-constexpr int kRawR = 21, kRawW = 43, kRawP = 44;
+constexpr int kRawR = 21, kRawW = 43, kRawP = 48;   // raw rows start at a 4-byte aligned column
 constexpr int kBlurR = 18, kBlurW = 37, kBlurP = 40;
 
 __device__ __forceinline__ int reflect101_dev(int p, int n) {
@@ -682,9 +771,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
                                                               const int* __restrict__ kpCount,
                                                               orbx_keypoint* __restrict__ outKps,
                                                               uint8_t* __restrict__ outDesc, int capacity) {
-    __shared__ uint8_t s_raw[kDescWaves][kRawW * kRawP];
-    __shared__ uint16_t s_hor[kDescWaves][kRawW * kBlurP];
-    __shared__ uint8_t s_blur[kDescWaves][kBlurW * kBlurP];
+    __shared__ __align__(16) uint8_t s_raw[kDescWaves][kRawW * kRawP];    // raw patch, later the blurred core
+    __shared__ __align__(16) uint16_t s_hor[kDescWaves][kRawW * kBlurP];
 
     const int frame = blockIdx.y;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -707,15 +795,32 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     const uint8_t* img = pyr + (long long)frame * frameStride + G.off;
     const int cx = __float2int_rn(kp.x), cy = __float2int_rn(kp.y);
 
-    uint8_t* raw = s_raw[wv];
+    uint8_t* rawBase = s_raw[wv];
     uint16_t* hor = s_hor[wv];
-    uint8_t* blur = s_blur[wv];
+    uint8_t* blur = rawBase;   // the raw patch is dead once the horizontal pass is done
 
+    // Patch rows cy-21 .. cy+21, columns cx-21 .. cx+21.  Interior keypoints fetch each row as
+    // 12 aligned dwords starting at the 4-byte aligned column xa <= cx-21 (ox = offset of the
+    // patch inside the tile); keypoints whose patch crosses the level edge take the byte
+    // path with REFLECT_101 indices.
+    const int px0 = cx - kRawR, py0 = cy - kRawR;
+    const int xa = px0 & ~3;
+    const bool interior = px0 >= 0 && py0 >= 0 && cx + kRawR < G.w && cy + kRawR < G.h && xa + kRawP <= G.pitch;
+    const int ox = interior ? px0 - xa : 0;
+    const uint8_t* raw = rawBase + ox;
     if (active) {
-        for (int i = lane; i < kRawW * kRawW; i += 64) {
-            const int r = i / kRawW, c = i - r * kRawW;
-            const int yy = reflect101_dev(cy - kRawR + r, G.h), xx = reflect101_dev(cx - kRawR + c, G.w);
-            raw[r * kRawP + c] = img[(long long)yy * G.pitch + xx];
+        if (interior) {
+            for (int i = lane; i < kRawW * (kRawP / 4); i += 64) {
+                const int r = i / (kRawP / 4), d = i - r * (kRawP / 4);
+                *reinterpret_cast<uint32_t*>(rawBase + r * kRawP + 4 * d) =
+                    *reinterpret_cast<const uint32_t*>(img + (long long)(py0 + r) * G.pitch + xa + 4 * d);
+            }
+        } else {
+            for (int i = lane; i < kRawW * kRawW; i += 64) {
+                const int r = i / kRawW, c = i - r * kRawW;
+                const int yy = reflect101_dev(py0 + r, G.h), xx = reflect101_dev(px0 + c, G.w);
+                rawBase[r * kRawP + c] = img[(long long)yy * G.pitch + xx];
+            }
         }
     }
     __syncthreads();
@@ -738,19 +843,34 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- separable 7-tap blur of the 37x37 core ----
-    for (int i = lane; active && i < kRawW * kBlurW; i += 64) {
-        const int r = i / kBlurW, c = i - r * kBlurW;   // output column c <-> raw columns c .. c+6
-        const uint8_t* p = raw + r * kRawP + c;
-        hor[r * kBlurP + c] = (uint16_t)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 48 * (p[2] + p[4]) + 56 * p[3]);
+    // ---- separable 7-tap blur of the 37x37 core, 8 outputs per work item ----
+    // horizontal: item = (raw row r, 8 output columns c0..c0+7) reads 14 bytes once
+    for (int i = lane; active && i < kRawW * 5; i += 64) {
+        const int r = i / 5, c0 = (i - r * 5) * 8;
+        const uint8_t* p = raw + r * kRawP + c0;
+        int v[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) v[k] = (c0 + k < kRawW) ? p[k] : 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (c0 + k < kBlurW)
+                hor[r * kBlurP + c0 + k] = (uint16_t)(18 * (v[k] + v[k + 6]) + 34 * (v[k + 1] + v[k + 5]) +
+                                                      48 * (v[k + 2] + v[k + 4]) + 56 * v[k + 3]);
     }
     __syncthreads();
-    for (int i = lane; active && i < kBlurW * kBlurW; i += 64) {
-        const int r = i / kBlurW, c = i - r * kBlurW;
-        const uint16_t* p = hor + r * kBlurP + c;
-        const uint32_t s = 18u * (p[0] + p[6 * kBlurP]) + 34u * (p[kBlurP] + p[5 * kBlurP]) +
-                           48u * (p[2 * kBlurP] + p[4 * kBlurP]) + 56u * p[3 * kBlurP];
-        blur[r * kBlurP + c] = (uint8_t)((s + 32768u) >> 16);
+    // vertical: item = (column c, 8 output rows r0..r0+7) reads 14 row sums once
+    for (int i = lane; active && i < kBlurW * 5; i += 64) {
+        const int seg = i / kBlurW, c = i - seg * kBlurW, r0 = seg * 8;
+        const uint16_t* p = hor + r0 * kBlurP + c;
+        uint32_t v[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) v[k] = (r0 + k < kRawW) ? p[k * kBlurP] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (r0 + k < kBlurW) {
+                const uint32_t sum = 18u * (v[k] + v[k + 6]) + 34u * (v[k + 1] + v[k + 5]) + 48u * (v[k + 2] + v[k + 4]) + 56u * v[k + 3];
+                blur[(r0 + k) * kBlurP + c] = (uint8_t)((sum + 32768u) >> 16);
+            }
     }
     __syncthreads();
 
@@ -815,7 +935,7 @@ struct orbx_extractor {
     OrbxErr* h_err = nullptr;      // pinned
     orbx_rect* d_rects = nullptr;
     int *d_xofs = nullptr, *d_yofs = nullptr;
-    short *d_xcoef = nullptr, *d_ycoef = nullptr;
+    uint32_t *d_xcoef = nullptr, *d_ycoef = nullptr;
     size_t tapAlloc = 0;
     // staging for the host entry points
     orbx_keypoint* d_outKps = nullptr;
@@ -861,7 +981,7 @@ static void resolve_timing(orbx_extractor* ex) {
     ex->evUsed = 0;
 }
 
-static void host_linear_taps(int ssize, int dsize, int* ofs, short* coef) {
+static void host_linear_taps(int ssize, int dsize, int* ofs, uint32_t* coef) {
     // cv::resize's coefficient set-up for INTER_LINEAR, 8-bit: 11-bit fixed point
     const double inv_scale = (double)dsize / ssize;
     const double scale = 1. / inv_scale;
@@ -872,8 +992,9 @@ static void host_linear_taps(int ssize, int dsize, int* ofs, short* coef) {
         if (s < 0) { f = 0; s = 0; }
         if (s >= ssize - 1) { f = 0; s = ssize - 1; }
         ofs[d] = s;
-        coef[2 * d] = (short)round_half_even_f((1.f - f) * 2048.f);
-        coef[2 * d + 1] = (short)round_half_even_f(f * 2048.f);
+        const uint32_t a0 = (uint32_t)(uint16_t)(short)round_half_even_f((1.f - f) * 2048.f);
+        const uint32_t a1 = (uint32_t)(uint16_t)(short)round_half_even_f(f * 2048.f);
+        coef[d] = a0 | (a1 << 16);
     }
 }
 
@@ -935,7 +1056,7 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
         L.invScale = 1 / L.scale;
         L.patchSize = (float)(int)(31 * ex->sf[l]);
         L.tapX = tapX; L.tapY = tapY;
-        tapX += L.w; tapY += L.h;
+        tapX += (L.w + 3) & ~3; tapY += (L.h + 3) & ~3;
     }
     ORBX_REQUIRE(maxNode <= 2800, "nfeatures too large for the on-chip quadtree (%d nodes per level, limit 2800)", maxNode);
     g.totalCells = cellBase;
@@ -943,6 +1064,13 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
     g.candTotal = candOff;
     g.kpTotal = kpOff;
     g.maxNodeCap = maxNode;
+    {
+        int mw = 0, mh = 0;
+        for (int l = 0; l < P.nlevels; ++l) { mw = std::max(mw, g.lv[l].wCell + 6); mh = std::max(mh, g.lv[l].hCell + 6); }
+        g.tileP = (mw + 3 + 3) & ~3;     // widest cell image + alignment shift, multiple of 4
+        g.tileR = mh;
+        g.fastLds = 2 * g.tileP * g.tileR + 2 * ((mw - 6) * (mh - 6) + 4);
+    }
 
     {
         const size_t qtLds = (size_t)maxNode * 56 + kQtThreads * sizeof(int);
@@ -965,20 +1093,25 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
     ORBX_HIP_TRY(hipMalloc((void**)&ex->d_cands, B * (size_t)g.candTotal * sizeof(OrbxCand)));
     ORBX_HIP_TRY(hipMalloc((void**)&ex->d_keyNode, B * (size_t)g.candTotal * sizeof(uint16_t)));
     ORBX_HIP_TRY(hipMalloc((void**)&ex->d_levelKps, B * (size_t)g.kpTotal * sizeof(OrbxLevelKp)));
-    std::vector<int> xo(tapX), yo(tapY);
-    std::vector<short> xc(2 * (size_t)tapX), yc(2 * (size_t)tapY);
+    std::vector<int> xo(tapX, 0), yo(tapY, 0);
+    std::vector<uint32_t> xc(tapX, 2048u), yc(tapY, 2048u);
     for (int l = 1; l < P.nlevels; ++l) {
-        host_linear_taps(g.lv[l - 1].w, g.lv[l].w, &xo[g.lv[l].tapX], &xc[2 * (size_t)g.lv[l].tapX]);
-        host_linear_taps(g.lv[l - 1].h, g.lv[l].h, &yo[g.lv[l].tapY], &yc[2 * (size_t)g.lv[l].tapY]);
+        host_linear_taps(g.lv[l - 1].w, g.lv[l].w, &xo[g.lv[l].tapX], &xc[g.lv[l].tapX]);
+        host_linear_taps(g.lv[l - 1].h, g.lv[l].h, &yo[g.lv[l].tapY], &yc[g.lv[l].tapY]);
+        // padding entries repeat the last column so that the 4-wide loads stay in range
+        for (int x = g.lv[l].w; x < ((g.lv[l].w + 3) & ~3); ++x) {
+            xo[g.lv[l].tapX + x] = xo[g.lv[l].tapX + g.lv[l].w - 1];
+            xc[g.lv[l].tapX + x] = xc[g.lv[l].tapX + g.lv[l].w - 1];
+        }
     }
-    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_xofs, tapX * sizeof(int)));
-    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_yofs, tapY * sizeof(int)));
-    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_xcoef, 2 * (size_t)tapX * sizeof(short)));
-    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_ycoef, 2 * (size_t)tapY * sizeof(short)));
+    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_xofs, std::max(tapX, 4) * sizeof(int)));
+    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_yofs, std::max(tapY, 4) * sizeof(int)));
+    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_xcoef, std::max(tapX, 4) * sizeof(uint32_t)));
+    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_ycoef, std::max(tapY, 4) * sizeof(uint32_t)));
     ORBX_HIP_TRY(hipMemcpy(ex->d_xofs, xo.data(), tapX * sizeof(int), hipMemcpyHostToDevice));
     ORBX_HIP_TRY(hipMemcpy(ex->d_yofs, yo.data(), tapY * sizeof(int), hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(ex->d_xcoef, xc.data(), 2 * (size_t)tapX * sizeof(short), hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(ex->d_ycoef, yc.data(), 2 * (size_t)tapY * sizeof(short), hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(ex->d_xcoef, xc.data(), tapX * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(ex->d_ycoef, yc.data(), tapY * sizeof(uint32_t), hipMemcpyHostToDevice));
     ORBX_HIP_TRY(hipMemcpy(ex->d_geo, &g, sizeof(g), hipMemcpyHostToDevice));
     ex->geoValid = true;
     return ORBX_OK;
@@ -1093,7 +1226,7 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
                            ex->d_yofs, ex->d_ycoef);
     }
     mark(ex, st);
-    hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nf), dim3(256), 0, st, ex->d_geo, ex->d_pyr, g.pyrBytes, ex->d_cands,
+    hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nf), dim3(kFastThreads), (size_t)g.fastLds, st, ex->d_geo, ex->d_pyr, g.pyrBytes, ex->d_cands,
                        ex->d_candCount, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->d_rects, ndyn, ex->d_err);
     mark(ex, st);
     const size_t qtLds = (size_t)g.maxNodeCap * 56 + kQtThreads * sizeof(int);
@@ -1123,10 +1256,11 @@ extern "C" orbx_status orbx_extract_batch_device(orbx_extractor* ex, const uint8
     orbx_status s = ensure_geometry(ex, width, height);
     if (s != ORBX_OK) return s;
     hipStream_t st = (hipStream_t)stream;   // taken literally: NULL is the device's default stream
-    dim3 grid((width + 255) / 256, height, n_frames);
+    dim3 grid((width + 16 * 64 - 1) / (16 * 64), height, n_frames);
+    const int aligned16 = ((((uintptr_t)d_images) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
     mark(ex, st);
-    hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, st, ex->d_geo, d_images, (long long)row_stride,
-                       (long long)frame_stride, ex->d_pyr, ex->geo.pyrBytes);
+    hipLaunchKernelGGL(k_copy_level0, grid, dim3(64), 0, st, ex->d_geo, d_images, (long long)row_stride,
+                       (long long)frame_stride, ex->d_pyr, ex->geo.pyrBytes, aligned16);
     return enqueue_batch(ex, n_frames, lap0, lap1, dyn_host, ndyn, d_keypoints, d_descriptors, capacity, d_counts, st);
 }
 
