@@ -204,7 +204,7 @@ def main():
         g2 = torch.Generator(device=dev); g2.manual_seed(600 + rank)
         dt_map = torch.randint(0, 256, (n_local, 32), dtype=torch.uint8, device=dev, generator=g2)
         part = torch.empty((NQ_MAP, 4), dtype=torch.int32, device=dev)
-        gathered = torch.empty((world, NQ_MAP, 4), dtype=torch.int32, device=dev)
+        gathered = torch.empty((world * NQ_MAP, 4), dtype=torch.int32, device=dev)
         ws = None
 
         def search():
@@ -212,7 +212,7 @@ def main():
             p, ws = A.knn_match2_device(dq, dt_map, base_index=base, out=part, workspace=ws)
             if world > 1:
                 dist.all_gather_into_tensor(gathered, p)
-                return A.knn2_merge_device(gathered)
+                return A.knn2_merge_device(gathered.view(world, NQ_MAP, 4))
             return p
         search(); torch.cuda.synchronize(); barrier()
         iters = 5

@@ -1,0 +1,153 @@
+// C++ host side above the C ABI (include/orbx.h): RAII mirror of ORB_SLAM3::ORBextractor
+// (include/ORBextractor.h:42-121) with the same constructor arguments, getters, public
+// members (mvImagePyramid, mvDynamicArea) and operator() contract.  Header only.
+//
+// orbx::Extractor works on plain buffers and is what this repository compiles and tests.
+// When OpenCV is available, define ORBX_WITH_OPENCV before including this header to get
+// ORB_SLAM3::ORBextractor with the reference's exact cv-typed signature on top of it; that
+// class is a drop-in for src/ORBextractor.cc (Frame, Tracking keep calling it unchanged).
+#ifndef ORBX_EXTRACTOR_HPP_
+#define ORBX_EXTRACTOR_HPP_
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../orbx.h"
+
+namespace orbx {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const char* m) : std::runtime_error(std::string("orbx: ") + m), status(s) {}
+};
+inline void check(orbx_status s) {
+    if (s != ORBX_OK) throw Error(s, orbx_last_error());
+}
+
+// Borderless host copy of one pyramid level (ORBextractor::mvImagePyramid element).
+struct Level {
+    int width = 0, height = 0;
+    std::vector<uint8_t> pixels;   // width * height, tightly packed
+};
+
+class Extractor {
+public:
+    // ORBextractor::ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+    // (ORBextractor.cc:477).  The device buffers are sized lazily from the first image.
+    Extractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = -1)
+        : nfeatures_(nfeatures), scaleFactor_(scaleFactor), nlevels_(nlevels), iniTh_(iniThFAST), minTh_(minThFAST),
+          device_(device) {}
+    ~Extractor() { if (h_) orbx_extractor_destroy(h_); }
+    Extractor(const Extractor&) = delete;
+    Extractor& operator=(const Extractor&) = delete;
+
+    int GetLevels() const { return nlevels_; }
+    float GetScaleFactor() const { return scaleFactor_; }
+    std::vector<float> GetScaleFactors() { ensure(752, 480); return sf_; }
+    std::vector<float> GetInverseScaleFactors() { ensure(752, 480); return isf_; }
+    std::vector<float> GetScaleSigmaSquares() { ensure(752, 480); return s2_; }
+    std::vector<float> GetInverseScaleSigmaSquares() { ensure(752, 480); return is2_; }
+
+    // operator(): returns monoIndex, or -1 for an empty image (ORBextractor.cc:1271-1399).
+    // keypoints / descriptors are resized to the number of keypoints (descriptors: n x 32).
+    int operator()(const uint8_t* image, int width, int height, ptrdiff_t stride, std::vector<orbx_keypoint>& keypoints,
+                   std::vector<uint8_t>& descriptors, const std::vector<int>& vLappingArea) {
+        if (!image || width <= 0 || height <= 0) { keypoints.clear(); descriptors.clear(); return -1; }
+        ensure(width, height);
+        const int cap = orbx_extractor_max_keypoints(h_);
+        keypoints.resize(cap);
+        descriptors.resize((size_t)cap * 32);
+        int n = 0, mono = 0;
+        check(orbx_extract(h_, image, width, height, stride, vLappingArea.at(0), vLappingArea.at(1),
+                           mvDynamicArea.empty() ? nullptr : mvDynamicArea.data(), (int)mvDynamicArea.size(),
+                           keypoints.data(), descriptors.data(), cap, &n, &mono));
+        keypoints.resize(n);
+        descriptors.resize((size_t)n * 32);
+        if (keepPyramid) fetch_pyramid();
+        return mono;
+    }
+
+    orbx_extractor* handle() { return h_; }
+
+    // public members of the reference class
+    std::vector<Level> mvImagePyramid;        // filled after each call when keepPyramid is set
+    std::vector<orbx_rect> mvDynamicArea;     // ORBextractor.h:95-96
+    bool keepPyramid = false;                  // Frame::ComputeStereoMatches reads the pyramid only in the
+                                               // CPU path; orbx_stereo_match uses the device copy directly
+
+private:
+    void ensure(int w, int h) {
+        if (h_ && w <= maxW_ && h <= maxH_) return;
+        if (h_) { orbx_extractor_destroy(h_); h_ = nullptr; }
+        maxW_ = w > maxW_ ? w : maxW_;
+        maxH_ = h > maxH_ ? h : maxH_;
+        orbx_params p{nfeatures_, scaleFactor_, nlevels_, iniTh_, minTh_, maxW_, maxH_, 1, device_};
+        check(orbx_extractor_create(&p, &h_));
+        sf_.resize(nlevels_); isf_.resize(nlevels_); s2_.resize(nlevels_); is2_.resize(nlevels_);
+        check(orbx_extractor_tables(h_, sf_.data(), isf_.data(), s2_.data(), is2_.data(), nullptr));
+    }
+    void fetch_pyramid() {
+        mvImagePyramid.resize(nlevels_);
+        for (int l = 0; l < nlevels_; ++l) {
+            Level& L = mvImagePyramid[l];
+            check(orbx_pyramid_level(h_, 0, l, nullptr, 0, &L.width, &L.height));
+            L.pixels.resize((size_t)L.width * L.height);
+            check(orbx_pyramid_level(h_, 0, l, L.pixels.data(), L.pixels.size(), &L.width, &L.height));
+        }
+    }
+    int nfeatures_; float scaleFactor_; int nlevels_, iniTh_, minTh_, device_;
+    int maxW_ = 0, maxH_ = 0;
+    orbx_extractor* h_ = nullptr;
+    std::vector<float> sf_, isf_, s2_, is2_;
+};
+
+}  // namespace orbx
+
+#ifdef ORBX_WITH_OPENCV
+#include <opencv2/core/core.hpp>
+namespace ORB_SLAM3 {
+// Same public surface as the reference class; link with -lorbx instead of compiling src/ORBextractor.cc.
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+        : impl_(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) { impl_.keepPyramid = true; }
+    int operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                   cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
+        if (_image.empty()) return -1;
+        cv::Mat image = _image.getMat();
+        CV_Assert(image.type() == CV_8UC1);
+        static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint), "cv::KeyPoint layout");
+        impl_.mvDynamicArea.clear();
+        for (const cv::Rect2i& r : mvDynamicArea) impl_.mvDynamicArea.push_back(orbx_rect{r.x, r.y, r.width, r.height});
+        std::vector<orbx_keypoint> kps;
+        std::vector<uint8_t> desc;
+        const int mono = impl_(image.data, image.cols, image.rows, (ptrdiff_t)image.step, kps, desc, vLappingArea);
+        _keypoints.resize(kps.size());
+        if (!kps.empty()) std::memcpy((void*)_keypoints.data(), kps.data(), kps.size() * sizeof(orbx_keypoint));
+        if (kps.empty()) _descriptors.release();
+        else { _descriptors.create((int)kps.size(), 32, CV_8U); std::memcpy(_descriptors.getMat().data, desc.data(), desc.size()); }
+        mvImagePyramid.resize(impl_.mvImagePyramid.size());
+        for (size_t l = 0; l < impl_.mvImagePyramid.size(); ++l) {
+            orbx::Level& L = impl_.mvImagePyramid[l];
+            mvImagePyramid[l] = cv::Mat(L.height, L.width, CV_8UC1, L.pixels.data());   // header over the host copy
+        }
+        return mono;
+    }
+    int GetLevels() { return impl_.GetLevels(); }
+    float GetScaleFactor() { return impl_.GetScaleFactor(); }
+    std::vector<float> GetScaleFactors() { return impl_.GetScaleFactors(); }
+    std::vector<float> GetInverseScaleFactors() { return impl_.GetInverseScaleFactors(); }
+    std::vector<float> GetScaleSigmaSquares() { return impl_.GetScaleSigmaSquares(); }
+    std::vector<float> GetInverseScaleSigmaSquares() { return impl_.GetInverseScaleSigmaSquares(); }
+    std::vector<cv::Mat> mvImagePyramid;
+    std::vector<cv::Rect2i> mvDynamicArea;
+    orbx::Extractor& impl() { return impl_; }
+private:
+    orbx::Extractor impl_;
+};
+}  // namespace ORB_SLAM3
+#endif  // ORBX_WITH_OPENCV
+#endif

@@ -1,0 +1,53 @@
+// Exercises the C++ host layer (include/orbx/*.hpp) end to end: extracts two images, runs
+// stereo matching and a kNN search, and dumps the results as raw binary for the Python test
+// to compare with the oracle.  usage: adapter_demo left.raw right.raw W H out_prefix
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <vector>
+
+#include "orbx/extractor.hpp"
+#include "orbx/matcher.hpp"
+
+static std::vector<uint8_t> slurp(const char* p) {
+    std::ifstream f(p, std::ios::binary);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+template <class T> static void dump(const std::string& p, const std::vector<T>& v) {
+    std::ofstream f(p, std::ios::binary);
+    f.write((const char*)v.data(), (std::streamsize)(v.size() * sizeof(T)));
+}
+
+int main(int argc, char** argv) {
+    if (argc < 6) { std::fprintf(stderr, "usage: %s left right W H prefix\n", argv[0]); return 2; }
+    try {
+        const int W = std::atoi(argv[3]), H = std::atoi(argv[4]);
+        std::vector<uint8_t> L = slurp(argv[1]), R = slurp(argv[2]);
+        if ((int)L.size() != W * H || (int)R.size() != W * H) { std::fprintf(stderr, "bad image size\n"); return 2; }
+        orbx::Extractor exL(1200, 1.2f, 8, 20, 7), exR(1200, 1.2f, 8, 20, 7);
+        exL.keepPyramid = true;
+        std::vector<orbx_keypoint> kL, kR;
+        std::vector<uint8_t> dL, dR;
+        std::vector<int> lap = {0, 0};
+        const int monoL = exL(L.data(), W, H, W, kL, dL, lap);
+        const int monoR = exR(R.data(), W, H, W, kR, dR, lap);
+        std::vector<uint8_t> empty_k;
+        std::vector<orbx_keypoint> ek; std::vector<uint8_t> ed;
+        const int monoEmpty = exL(nullptr, 0, 0, 0, ek, ed, lap);
+        std::vector<float> uR, depth;
+        const float mbf = 47.90639384423901f, fx = 435.2046959714599f;
+        orbx::ComputeStereoMatches(exL, exR, kL, dL, kR, dR, mbf, mbf / fx, uR, depth);
+        std::vector<orbx_match2> knn = orbx::KnnMatch2(dL.data(), (int)kL.size(), dR.data(), (int64_t)kR.size());
+        std::string pre = argv[5];
+        dump(pre + "_kL.bin", kL); dump(pre + "_dL.bin", dL); dump(pre + "_kR.bin", kR); dump(pre + "_dR.bin", dR);
+        dump(pre + "_uR.bin", uR); dump(pre + "_depth.bin", depth); dump(pre + "_knn.bin", knn);
+        dump(pre + "_pyr3.bin", exL.mvImagePyramid.at(3).pixels);
+        std::printf("monoL=%d monoR=%d monoEmpty=%d nL=%zu nR=%zu levels=%d sf1=%.9g\n", monoL, monoR, monoEmpty, kL.size(),
+                    kR.size(), exL.GetLevels(), exL.GetScaleFactors().at(1));
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

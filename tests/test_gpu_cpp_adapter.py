@@ -1,0 +1,45 @@
+"""The C++ host layer (include/orbx/extractor.hpp, matcher.hpp) over the C ABI, run as a
+separate native program and compared with the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from orb_slam3_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "orb_slam3_amd", "lib", "adapter_demo")
+MBF, FX = np.float32(47.90639384423901), np.float32(435.2046959714599)
+
+
+def test_cpp_adapter_matches_oracle(oracle, tmp_path):
+    assert os.path.exists(DEMO), "adapter_demo not built (make -C orb_slam3_amd/csrc)"
+    from orb_slam3_amd import KP_DTYPE, MATCH2_DTYPE
+    L, R = synth.stereo_pair(752, 480, 7)
+    (tmp_path / "l.raw").write_bytes(L.tobytes())
+    (tmp_path / "r.raw").write_bytes(R.tobytes())
+    pre = str(tmp_path / "o")
+    out = subprocess.run([DEMO, str(tmp_path / "l.raw"), str(tmp_path / "r.raw"), "752", "480", pre],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "monoEmpty=-1" in out.stdout and "levels=8" in out.stdout
+    eL, eR = oracle.Extractor(1200), oracle.Extractor(1200)
+    kL, dL, mL = eL(L, (0, 0))
+    kR, dR, mR = eR(R, (0, 0))
+    assert f"monoL={mL} monoR={mR}" in out.stdout
+    rd = lambda name, dt: np.fromfile(pre + name, dtype=dt)
+    assert np.array_equal(rd("_kL.bin", KP_DTYPE), kL) and np.array_equal(rd("_kR.bin", KP_DTYPE), kR)
+    assert np.array_equal(rd("_dL.bin", np.uint8).reshape(-1, 32), dL)
+    assert np.array_equal(rd("_dR.bin", np.uint8).reshape(-1, 32), dR)
+    pl = [eL.pyramid_level(l) for l in range(8)]
+    pr = [eR.pyramid_level(l) for l in range(8)]
+    uR, depth, _, _ = oracle.stereo_match(kL, dL, kR, dR, pl, pr, eL.scale_factors, eL.inv_scale_factors,
+                                          float(MBF), float(MBF / FX))
+    assert np.array_equal(rd("_uR.bin", np.float32), uR) and np.array_equal(rd("_depth.bin", np.float32), depth)
+    knn = rd("_knn.bin", MATCH2_DTYPE)
+    ref = oracle.knn2(dL, dR)
+    assert np.array_equal(np.stack([knn["idx0"], knn["dist0"], knn["idx1"], knn["dist1"]], 1), ref)
+    assert np.array_equal(rd("_pyr3.bin", np.uint8), pl[3].ravel())
