@@ -70,57 +70,105 @@ extern "C" orbx_status orbx_descriptor_distance(const uint8_t* a, const uint8_t*
 // Ties: strict '<' while scanning ascending indices keeps the lowest index, and the merge
 // is lexicographic on (distance, index), which is what a single sequential scan gives.
 // ======================================================================================
-constexpr int kQpl = 2;
+constexpr int kQpl = 4;        // queries per lane
 constexpr int kKnnWaves = 4;
+constexpr int kRowsPerIter = 4;   // train rows fetched (scalar) and applied per loop trip
+
+// Per-query register state.  Four named instances (not an array) so that everything stays in
+// VGPRs: a runtime-indexed array of these would be placed in scratch memory.
+struct KnnQuery {
+    uint32_t q[8];
+    int best, second, bestIdx, secondIdx;
+    int qi;
+};
+
+__device__ __forceinline__ void knn_load(KnnQuery& s, const uint32_t* __restrict__ query, int qi, int nq) {
+    s.qi = qi;
+    const uint4* src = reinterpret_cast<const uint4*>(query + 8ll * (qi < nq ? qi : 0));
+    const uint4 a = src[0], b = src[1];
+    s.q[0] = a.x; s.q[1] = a.y; s.q[2] = a.z; s.q[3] = a.w;
+    s.q[4] = b.x; s.q[5] = b.y; s.q[6] = b.z; s.q[7] = b.w;
+    s.best = INT_MAX; s.second = INT_MAX; s.bestIdx = -1; s.secondIdx = -1;
+}
+
+__device__ __forceinline__ void knn_update(KnnQuery& s, int d, int gj) {
+    if (d < s.second) {
+        if (d < s.best) { s.second = s.best; s.secondIdx = s.bestIdx; s.best = d; s.bestIdx = gj; }
+        else { s.second = d; s.secondIdx = gj; }
+    }
+}
+
+__device__ __forceinline__ int knn_dist(const KnnQuery& s, const uint32_t (&t)[8]) {
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += __popc(s.q[k] ^ t[k]);
+    return acc;
+}
+
+// kRowsPerIter (= 4) rows against one query: the bookkeeping is entered only when the smallest
+// of the four distances beats the current second best, and then replays the rows in
+// ascending index order (strict '<' keeps the lowest index among equal distances).
+__device__ __forceinline__ void knn_rows4(KnnQuery& s, const uint32_t (&t0)[8], const uint32_t (&t1)[8],
+                                          const uint32_t (&t2)[8], const uint32_t (&t3)[8], int gj) {
+    const int d0 = knn_dist(s, t0), d1 = knn_dist(s, t1), d2 = knn_dist(s, t2), d3 = knn_dist(s, t3);
+    const int m = min(min(d0, d1), min(d2, d3));
+    if (m < s.second) {
+        knn_update(s, d0, gj); knn_update(s, d1, gj + 1); knn_update(s, d2, gj + 2); knn_update(s, d3, gj + 3);
+    }
+}
+
+__device__ __forceinline__ void knn_store(const KnnQuery& s, int nq, orbx_match2* __restrict__ part) {
+    if (s.qi < nq) {
+        orbx_match2 m;
+        m.idx0 = s.bestIdx; m.dist0 = s.best; m.idx1 = s.secondIdx; m.dist1 = s.second;
+        part[s.qi] = m;
+    }
+}
 
 __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restrict__ query, int nq,
                                                           const uint32_t* __restrict__ train, long long nt,
                                                           long long chunkLen, long long baseIndex,
                                                           orbx_match2* __restrict__ part) {
+    static_assert(kQpl == 4 && kRowsPerIter == 4, "the body below is written out for 4 x 4");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int group = blockIdx.x * kKnnWaves + wave;
     const long long j0 = (long long)blockIdx.y * chunkLen;
     const long long j1 = min(nt, j0 + chunkLen);
-
-    uint32_t q[kQpl][8];
-    int best[kQpl], second[kQpl], bestIdx[kQpl], secondIdx[kQpl];
-    int qi[kQpl];
-#pragma unroll
-    for (int i = 0; i < kQpl; ++i) {
-        qi[i] = group * 64 * kQpl + i * 64 + lane;
-        const bool ok = qi[i] < nq;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) q[i][k] = ok ? query[8ll * qi[i] + k] : 0u;
-        best[i] = INT_MAX; second[i] = INT_MAX; bestIdx[i] = -1; secondIdx[i] = -1;
-    }
     if (group * 64 * kQpl >= nq) return;
 
-    for (long long j = j0; j < j1; ++j) {
-        const uint32_t* __restrict__ t = train + 8ll * j;   // wave-uniform address: scalar loads
-        uint32_t tw[8];
+    KnnQuery a, b, c, d;
+    const int q0 = group * 64 * kQpl + lane;
+    knn_load(a, query, q0, nq);
+    knn_load(b, query, q0 + 64, nq);
+    knn_load(c, query, q0 + 128, nq);
+    knn_load(d, query, q0 + 192, nq);
+
+    long long j = j0;
+    for (; j + kRowsPerIter <= j1; j += kRowsPerIter) {
+        const uint32_t* __restrict__ t = train + 8ll * j;   // wave-uniform: scalar loads
+        uint32_t t0[8], t1[8], t2[8], t3[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) tw[k] = t[k];
+        for (int k = 0; k < 8; ++k) { t0[k] = t[k]; t1[k] = t[8 + k]; t2[k] = t[16 + k]; t3[k] = t[24 + k]; }
         const int gj = (int)(baseIndex + j);
-#pragma unroll
-        for (int i = 0; i < kQpl; ++i) {
-            int d = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) d += __popc(q[i][k] ^ tw[k]);
-            if (d < second[i]) {
-                if (d < best[i]) { second[i] = best[i]; secondIdx[i] = bestIdx[i]; best[i] = d; bestIdx[i] = gj; }
-                else { second[i] = d; secondIdx[i] = gj; }
-            }
-        }
+        knn_rows4(a, t0, t1, t2, t3, gj);
+        knn_rows4(b, t0, t1, t2, t3, gj);
+        knn_rows4(c, t0, t1, t2, t3, gj);
+        knn_rows4(d, t0, t1, t2, t3, gj);
     }
+    for (; j < j1; ++j) {
+        const uint32_t* __restrict__ t = train + 8ll * j;
+        uint32_t t0[8];
 #pragma unroll
-    for (int i = 0; i < kQpl; ++i) {
-        if (qi[i] < nq) {
-            orbx_match2 m;
-            m.idx0 = bestIdx[i]; m.dist0 = best[i]; m.idx1 = secondIdx[i]; m.dist1 = second[i];
-            part[(long long)blockIdx.y * nq + qi[i]] = m;
-        }
+        for (int k = 0; k < 8; ++k) t0[k] = t[k];
+        const int gj = (int)(baseIndex + j);
+        knn_update(a, knn_dist(a, t0), gj);
+        knn_update(b, knn_dist(b, t0), gj);
+        knn_update(c, knn_dist(c, t0), gj);
+        knn_update(d, knn_dist(d, t0), gj);
     }
+    orbx_match2* out = part + (long long)blockIdx.y * nq;
+    knn_store(a, nq, out); knn_store(b, nq, out); knn_store(c, nq, out); knn_store(d, nq, out);
 }
 
 __device__ __forceinline__ bool lex_less(int d0, int i0, int d1, int i1) { return d0 < d1 || (d0 == d1 && i0 < i1); }
@@ -165,7 +213,7 @@ extern "C" orbx_status orbx_hamming_knn2_device(const uint8_t* d_query, int n_qu
     if (n_query == 0) return ORBX_OK;
     ORBX_REQUIRE(d_query && d_out && (n_train == 0 || d_train), "null argument");
     ORBX_REQUIRE(base_index >= 0 && base_index + n_train <= (int64_t)INT_MAX, "train index does not fit 32 bits");
-    ORBX_REQUIRE((((uintptr_t)d_query | (uintptr_t)d_train) & 3) == 0, "descriptors must be 4-byte aligned");
+    ORBX_REQUIRE((((uintptr_t)d_query | (uintptr_t)d_train) & 15) == 0, "descriptor arrays must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int chunks = n_train > 0 ? knn2_chunks(n_query, n_train) : 0;
     if (chunks > 0) {
