@@ -55,6 +55,15 @@ __constant__ signed char c_pattern[1024] = {
 // umax[v]: half width of row v of the radius-15 disc (ORBextractor.cc:520-535)
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
+// Workgroups are dealt to the 8 XCDs (each with its own L2) round-robin in launch order.
+// xcd_remap turns the linear block id into a logical id such that every XCD works on one
+// contiguous run of logical ids, so blocks that touch neighbouring data share an L2.
+// A bijection for any grid size; placement only affects speed, never results.
+__device__ __forceinline__ int xcd_remap(int lin, int nBlocks) {
+    const int q = nBlocks >> 3, r = nBlocks & 7, xcd = lin & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+}
+
 struct OrbxErr {
     int cand_overflow;   // a level produced more FAST candidates than candCap
     int kp_overflow;     // quadtree list / level keypoints exceeded their capacity
@@ -79,11 +88,12 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__
                                                 const int* __restrict__ yofs, const uint32_t* __restrict__ ycoef) {
     const OrbxLevelGeo& S = geo->lv[level - 1];
     const OrbxLevelGeo& D = geo->lv[level];
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int fz = blockIdx.z;
     const int y = blockIdx.y;
+    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (x4 >= D.w) return;
-    const uint8_t* src = pyr + (long long)blockIdx.z * frameStride + S.off;
-    uint8_t* dst = pyr + (long long)blockIdx.z * frameStride + D.off;
+    const uint8_t* src = pyr + (long long)fz * frameStride + S.off;
+    uint8_t* dst = pyr + (long long)fz * frameStride + D.off;
     const int sy0 = yofs[D.tapY + y];
     const int sy1 = min(sy0 + 1, S.h - 1);
     const uint32_t yc = ycoef[D.tapY + y];
@@ -207,13 +217,17 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     uint8_t* strength = tile + P * R;
     unsigned short* s_queue = reinterpret_cast<unsigned short*>(strength + P * R);
 
-    const int frame = blockIdx.y;
+    // neighbouring cells overlap by 6 pixels: keep them on one XCD (see xcd_remap)
+    const int nCellsAll = gridDim.x;
+    const int logical = xcd_remap(blockIdx.y * nCellsAll + blockIdx.x, nCellsAll * gridDim.y);
+    const int frame = logical / nCellsAll;
+    const int cellAll = logical - frame * nCellsAll;
     int level = 0;
     const int nl = geo->nlevels;
     for (int l = 1; l < nl; ++l)
-        if ((int)blockIdx.x >= geo->lv[l].cellBase) level = l;
+        if (cellAll >= geo->lv[l].cellBase) level = l;
     const OrbxLevelGeo& G = geo->lv[level];
-    const int cell = blockIdx.x - G.cellBase;           // index among processed cells, row-major
+    const int cell = cellAll - G.cellBase;              // index among processed cells, row-major
     const int ci = cell / G.nColsP, cj = cell - ci * G.nColsP;
     const int maxBX = G.w - kOrbxMinBorder, maxBY = G.h - kOrbxMinBorder;
     const int x0 = kOrbxMinBorder + cj * G.wCell, y0 = kOrbxMinBorder + ci * G.hCell;
@@ -774,9 +788,11 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     __shared__ __align__(16) uint8_t s_raw[kDescWaves][kRawW * kRawP];    // raw patch, later the blurred core
     __shared__ __align__(16) uint16_t s_hor[kDescWaves][kRawW * kBlurP];
 
-    const int frame = blockIdx.y;
+    // keypoints of one frame read the same few level images: keep a frame on one XCD
+    const int logicalBlock = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int frame = logicalBlock / gridDim.x;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ordinal = blockIdx.x * kDescWaves + wv;
+    const int ordinal = (logicalBlock - frame * gridDim.x) * kDescWaves + wv;
     const int nl = geo->nlevels;
     int level = -1, idx = 0;
     for (int l = 0; l < nl; ++l) {
