@@ -162,29 +162,45 @@ __global__ __launch_bounds__(256) void k_copy_level0(const OrbxFrameGeo* __restr
 // ======================================================================================
 // LDS tile geometry is fixed per handle: pitch P (multiple of 4, >= widest cell image + 3 for
 // the alignment shift) and R rows; both come from the level geometry (OrbxFrameGeo::tileP/R).
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 pk_max(us2 a, us2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ us2 pk_min(us2 a, us2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ us2 pk_swap(us2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+
+// Arc strength of the pixel at (x, y): with p[k] the 16 circle pixels and v the centre,
+//   strength = max( v - min_arcs(max of 9 contiguous p),  max_arcs(min of 9 contiguous p) - v )
+// which equals max over the 16 arcs of max(min(v - p), -max(v - p)) (cornerScore<16> before its
+// "- 1").  Sliding max / min by doubling (2, 4, 8, then 9) on packed 16-bit pairs: register k
+// holds (p[k], p[k+8]), so one packed op advances arcs k and k+8 together; the second half of
+// the cyclic sequence is the same registers with their halves swapped.
 __device__ __forceinline__ int fast_strength_lds(const uint8_t* t, int P, int x, int y) {
-    // d[k] = centre - circle[k]; strength = max over the 16 arcs of nine of
-    // max(min(d), -max(d)).  Sliding minima / maxima by doubling: 2, 4, 8, then 9.
     const uint8_t* c = t + y * P + x;
     const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * P];          d[1] = v - c[3 * P + 1];   d[2] = v - c[2 * P + 2];   d[3] = v - c[P + 3];
-    d[4] = v - c[3];              d[5] = v - c[-P + 3];      d[6] = v - c[-2 * P + 2];  d[7] = v - c[-3 * P + 1];
-    d[8] = v - c[-3 * P];         d[9] = v - c[-3 * P - 1];  d[10] = v - c[-2 * P - 2]; d[11] = v - c[-P - 3];
-    d[12] = v - c[-3];            d[13] = v - c[P - 3];      d[14] = v - c[2 * P - 2];  d[15] = v - c[3 * P - 1];
-    int mn2[16], mx2[16], mn4[16], mx4[16];
+    us2 E[16];
+    E[0] = us2{c[3 * P], c[-3 * P]};           E[1] = us2{c[3 * P + 1], c[-3 * P - 1]};
+    E[2] = us2{c[2 * P + 2], c[-2 * P - 2]};   E[3] = us2{c[P + 3], c[-P - 3]};
+    E[4] = us2{c[3], c[-3]};                   E[5] = us2{c[-P + 3], c[P - 3]};
+    E[6] = us2{c[-2 * P + 2], c[2 * P - 2]};   E[7] = us2{c[-3 * P + 1], c[3 * P - 1]};
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { mn2[k] = min(d[k], d[(k + 1) & 15]); mx2[k] = max(d[k], d[(k + 1) & 15]); }
+    for (int k = 0; k < 8; ++k) E[8 + k] = pk_swap(E[k]);
+    us2 hi2[10], lo2[10], hi4[12], lo4[12];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
-    int best = -255;
+    for (int k = 0; k < 8; ++k) { hi2[k] = pk_max(E[k], E[k + 1]); lo2[k] = pk_min(E[k], E[k + 1]); }
+    hi2[8] = pk_swap(hi2[0]); hi2[9] = pk_swap(hi2[1]); lo2[8] = pk_swap(lo2[0]); lo2[9] = pk_swap(lo2[1]);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int mn9 = min(min(mn4[k], mn4[(k + 4) & 15]), d[(k + 8) & 15]);
-        const int mx9 = max(max(mx4[k], mx4[(k + 4) & 15]), d[(k + 8) & 15]);
-        best = max(best, max(mn9, -mx9));
+    for (int k = 0; k < 8; ++k) { hi4[k] = pk_max(hi2[k], hi2[k + 2]); lo4[k] = pk_min(lo2[k], lo2[k + 2]); }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { hi4[8 + k] = pk_swap(hi4[k]); lo4[8 + k] = pk_swap(lo4[k]); }
+    us2 A = us2{65535, 65535}, B = us2{0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const us2 hi9 = pk_max(pk_max(hi4[k], hi4[k + 4]), E[k + 8]);   // max of p[k .. k+8] | p[k+8 .. k+16]
+        const us2 lo9 = pk_min(pk_min(lo4[k], lo4[k + 4]), E[k + 8]);
+        A = pk_min(A, hi9);
+        B = pk_max(B, lo9);
     }
-    return best;
+    const int a = min((int)A.x, (int)A.y), bb = max((int)B.x, (int)B.y);
+    return max(v - a, bb - v);
 }
 
 __device__ __forceinline__ int score_at(int strength, int th) { return strength > th ? strength - 1 : 0; }
@@ -255,39 +271,61 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     uint8_t* T = tile + ox;               // T[y * P + x], x in cell coordinates
     uint8_t* S = strength + ox;
     if (iw > 0 && ih > 0) {
-        // (A) quick reject: an arc of 9 contiguous circle pixels contains one pixel of every
-        // antipodal pair, so all four pairs {0,8} {4,12} {2,10} {6,14} need a member beyond the
-        // (lower) threshold on the same side.  Survivors are queued densely.
-        const float invW = 1.0f / (float)iw;
-        const int total = iw * ih;
-        for (int i0 = 0; i0 < total; i0 += kFastThreads) {
-            const int i = i0 + tid;
-            bool pass = false;
-            int x = 0, y = 0;
-            if (i < total) {
-                y = (int)(((float)i + 0.5f) * invW);
-                x = i - y * iw + 3;
-                y += 3;
-                const uint8_t* c = T + y * P + x;
-                const int v = c[0];
-                const int hi = v + lowTh, lo = v - lowTh;
-                const int p0 = c[3 * P], p8 = c[-3 * P], p4 = c[3], p12 = c[-3];
-                bool dark = (p0 < lo || p8 < lo) && (p4 < lo || p12 < lo);
-                bool bright = (p0 > hi || p8 > hi) && (p4 > hi || p12 > hi);
-                if (dark || bright) {
-                    const int p2 = c[2 * P + 2], p10 = c[-2 * P - 2], p6 = c[-2 * P + 2], p14 = c[2 * P - 2];
-                    dark = dark && (p2 < lo || p10 < lo) && (p6 < lo || p14 < lo);
-                    bright = bright && (p2 > hi || p10 > hi) && (p6 > hi || p14 > hi);
-                    pass = dark || bright;
-                }
+        // (A) quick reject.  An arc of 9 contiguous circle pixels contains one pixel of every
+        // antipodal pair, so a corner needs, on one side of the (lower) threshold, a member of
+        // {0,8} (the pixels 3 rows below / above) AND a member of {4,12} (3 columns right / left).
+        // The testable pixels are cut into horizontal bands; a lane walks down one column of one
+        // band with that column's 7 rows (y-3 .. y+3) in registers, so each further pixel costs
+        // three LDS byte reads.  Survivors are collected in a per-lane row mask and queued at the
+        // end of the walk (queue order is irrelevant).
+        const int bands = max(1, kFastThreads / iw);
+        const int bandRows = (ih + bands - 1) / bands;
+        const int band = tid / iw, col = tid - band * iw;
+        const bool laneOn = band < bands;
+        const int x = 3 + col;
+        const int yBeg = 3 + band * bandRows;
+        const int yEnd = laneOn ? min(yBeg + bandRows, 3 + ih) : 0;
+        for (int chunk = 0; chunk < bandRows; chunk += 28) {
+            const int yc = yBeg + chunk;                       // first row of this chunk
+            const int rows = min(28, bandRows - chunk);        // uniform
+            const uint8_t* c = T + (laneOn ? yc : 3) * P + (laneOn ? x : 3);
+            int w0 = c[-3 * P], w1 = c[-2 * P], w2 = c[-P], w3 = c[0], w4 = c[P], w5 = c[2 * P], w6 = c[3 * P];
+            unsigned mask = 0, bit = 1;   // bit i of mask = row yc + i survives
+            // one row: centre = a3, above = a0, below = a6; afterwards a0 receives row y + 4
+#define ORBX_FAST_ROW(a0, a1, a2, a3, a4, a5, a6, r)                                              \
+            if ((r) < rows) {                                                                         \
+                const int v = a3, lo = v - lowTh, hi = v + lowTh;                                     \
+                const int pl = c[-3], pr = c[3];                                                      \
+                const int dmax = max(min(a0, a6), min(pl, pr));   /* dark: both pairs have one < lo */ \
+                const int bmin = min(max(a0, a6), max(pl, pr));   /* bright: both pairs have one > hi */\
+                const bool pass = (dmax < lo) || (bmin > hi);                                         \
+                mask |= pass ? bit : 0u;                                                              \
+                bit <<= 1;                                                                            \
+                c += P;                                                                               \
+                a0 = c[3 * P];                                                                        \
             }
-            const unsigned long long bal = __ballot(pass);
-            if (bal) {
-                const int lane = tid & 63;
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_nQueue, __popcll(bal));
-                base = __shfl(base, 0);
-                if (pass) s_queue[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(x | (y << 7));
+            for (int r = 0; r < rows; r += 7) {
+                ORBX_FAST_ROW(w0, w1, w2, w3, w4, w5, w6, r + 0)
+                ORBX_FAST_ROW(w1, w2, w3, w4, w5, w6, w0, r + 1)
+                ORBX_FAST_ROW(w2, w3, w4, w5, w6, w0, w1, r + 2)
+                ORBX_FAST_ROW(w3, w4, w5, w6, w0, w1, w2, r + 3)
+                ORBX_FAST_ROW(w4, w5, w6, w0, w1, w2, w3, r + 4)
+                ORBX_FAST_ROW(w5, w6, w0, w1, w2, w3, w4, r + 5)
+                ORBX_FAST_ROW(w6, w0, w1, w2, w3, w4, w5, r + 6)
+            }
+#undef ORBX_FAST_ROW
+            // drop rows past the lane's band / the cell
+            const int valid = yEnd - yc;
+            unsigned m = (valid <= 0) ? 0u : (valid >= 32 ? mask : (mask & ((1u << valid) - 1u)));
+            int cnt = 0;
+            cnt = __popc(m);
+            if (cnt) {
+                int base = atomicAdd(&s_nQueue, cnt);
+                while (m) {
+                    const int i = __ffs(m) - 1;
+                    m &= m - 1;
+                    s_queue[base++] = (unsigned short)(x | ((yc + i) << 7));
+                }
             }
         }
     }
@@ -343,6 +381,16 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     const float border = (float)kOrbxMinBorder;
     OrbxCand* out = cands + (long long)frame * geo->candTotal + G.candOff;
     int* counter = candCount + frame * nl + level;
+    // Without erase rectangles every kept corner is emitted, so the cell reserves its output
+    // range with ONE global atomic (the per-level counter is shared by hundreds of cells);
+    // with rectangles the survivors are not known in advance and each takes its own slot.
+    const bool reserve = nrects == 0;
+    if (reserve) {
+        __syncthreads();   // everyone has read the counters that are about to be reused
+        if (tid == 0) { s_nQueue = atomicAdd(counter, n); s_nIni = 0; }   // s_nQueue / s_nIni reused: base / cursor
+        __syncthreads();
+    }
+    const int base = reserve ? s_nQueue : 0;
     for (int q = tid; q < nQueue; q += kFastThreads) {
         const int rec = s_queue[q];
         const int lx = rec & 127, ly = rec >> 7;
@@ -362,7 +410,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
             if (fixed) break;   // further applications reproduce the same values and the same rect test
         }
         if (erased) continue;
-        const int pos = atomicAdd(counter, 1);
+        const int pos = reserve ? base + atomicAdd(&s_nIni, 1) : atomicAdd(counter, 1);
         if (pos < G.candCap) {
             OrbxCand c;
             c.x = x; c.y = y; c.response = (float)sc;
