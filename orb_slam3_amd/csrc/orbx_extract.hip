@@ -49,7 +49,7 @@ extern "C" int orbx_device_count(void) {
 // ======================================================================================
 // device tables
 // ======================================================================================
-__constant__ signed char c_pattern[1024] = {
+__constant__ __align__(16) signed char c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
 // umax[v]: half width of row v of the radius-15 disc (ORBextractor.cc:520-535)
@@ -82,6 +82,8 @@ __device__ __forceinline__ int pick_byte(unsigned long long lo, unsigned long lo
     return (int)((v >> ((k & 7) * 8)) & 255ull);
 }
 
+constexpr int kResizeRows = 4;   // output rows per lane: taps are fetched once, source rows are reused
+
 __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__ geo, int level,
                                                 uint8_t* __restrict__ pyr, long long frameStride,
                                                 const int* __restrict__ xofs, const uint32_t* __restrict__ xcoef,
@@ -89,50 +91,70 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__
     const OrbxLevelGeo& S = geo->lv[level - 1];
     const OrbxLevelGeo& D = geo->lv[level];
     const int fz = blockIdx.z;
-    const int y = blockIdx.y;
+    const int yFirst = blockIdx.y * kResizeRows;
     const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (x4 >= D.w) return;
     const uint8_t* src = pyr + (long long)fz * frameStride + S.off;
     uint8_t* dst = pyr + (long long)fz * frameStride + D.off;
-    const int sy0 = yofs[D.tapY + y];
-    const int sy1 = min(sy0 + 1, S.h - 1);
-    const uint32_t yc = ycoef[D.tapY + y];
-    const int b0 = (int)(yc & 0xFFFFu), b1 = (int)(yc >> 16);
-    const uint8_t* r0 = src + (long long)sy0 * S.pitch;
-    const uint8_t* r1 = src + (long long)sy1 * S.pitch;
     const int4 o = *reinterpret_cast<const int4*>(xofs + D.tapX + x4);        // padded to a multiple of 4
     const uint4 c = *reinterpret_cast<const uint4*>(xcoef + D.tapX + x4);
     const int so[4] = {o.x, o.y, o.z, o.w};
     const uint32_t co[4] = {c.x, c.y, c.z, c.w};
     const int last = min(o.w + 1, S.w - 1);
     const int base = o.x & ~3;
-    uint32_t packed = 0;
-    if (last - base < 16) {
-        const uint32_t* p0 = reinterpret_cast<const uint32_t*>(r0 + base);
-        const uint32_t* p1 = reinterpret_cast<const uint32_t*>(r1 + base);
-        const unsigned long long lo0 = p0[0] | ((unsigned long long)p0[1] << 32), hi0 = p0[2] | ((unsigned long long)p0[3] << 32);
-        const unsigned long long lo1 = p1[0] | ((unsigned long long)p1[1] << 32), hi1 = p1[2] | ((unsigned long long)p1[3] << 32);
+    const bool window = last - base < 16;
+    int k0[4], k1[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k0 = so[i] - base, k1 = min(so[i] + 1, S.w - 1) - base;
-            const int a0 = (int)(co[i] & 0xFFFFu), a1 = (int)(co[i] >> 16);
-            const int t0 = pick_byte(lo0, hi0, k0) * a0 + pick_byte(lo0, hi0, k1) * a1;
-            const int t1 = pick_byte(lo1, hi1, k0) * a0 + pick_byte(lo1, hi1, k1) * a1;
-            const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 255) << (8 * i);
-        }
-    } else {
+    for (int i = 0; i < 4; ++i) { k0[i] = so[i] - base; k1[i] = min(so[i] + 1, S.w - 1) - base; }
+
+    // the 16-byte window of the previous lower source row is kept: consecutive output rows
+    // usually continue from it (sy0 of this row == sy1 of the previous one)
+    int heldRow = -1;
+    unsigned long long heldLo = 0, heldHi = 0;
+    for (int r = 0; r < kResizeRows; ++r) {
+        const int y = yFirst + r;
+        if (y >= D.h) break;
+        const int sy0 = yofs[D.tapY + y];
+        const int sy1 = min(sy0 + 1, S.h - 1);
+        const uint32_t yc = ycoef[D.tapY + y];
+        const int b0 = (int)(yc & 0xFFFFu), b1 = (int)(yc >> 16);
+        const uint8_t* r0 = src + (long long)sy0 * S.pitch;
+        const uint8_t* r1 = src + (long long)sy1 * S.pitch;
+        uint32_t packed = 0;
+        if (window) {
+            unsigned long long lo0, hi0, lo1, hi1;
+            if (sy0 == heldRow) { lo0 = heldLo; hi0 = heldHi; }
+            else {
+                const uint32_t* p0 = reinterpret_cast<const uint32_t*>(r0 + base);
+                lo0 = p0[0] | ((unsigned long long)p0[1] << 32); hi0 = p0[2] | ((unsigned long long)p0[3] << 32);
+            }
+            if (sy1 == sy0) { lo1 = lo0; hi1 = hi0; }
+            else {
+                const uint32_t* p1 = reinterpret_cast<const uint32_t*>(r1 + base);
+                lo1 = p1[0] | ((unsigned long long)p1[1] << 32); hi1 = p1[2] | ((unsigned long long)p1[3] << 32);
+            }
+            heldRow = sy1; heldLo = lo1; heldHi = hi1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int sx0 = so[i], sx1 = min(sx0 + 1, S.w - 1);
-            const int a0 = (int)(co[i] & 0xFFFFu), a1 = (int)(co[i] >> 16);
-            const int t0 = r0[sx0] * a0 + r0[sx1] * a1;
-            const int t1 = r1[sx0] * a0 + r1[sx1] * a1;
-            const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
-            packed |= (uint32_t)(v & 255) << (8 * i);
+            for (int i = 0; i < 4; ++i) {
+                const int a0 = (int)(co[i] & 0xFFFFu), a1 = (int)(co[i] >> 16);
+                const int t0 = pick_byte(lo0, hi0, k0[i]) * a0 + pick_byte(lo0, hi0, k1[i]) * a1;
+                const int t1 = pick_byte(lo1, hi1, k0[i]) * a0 + pick_byte(lo1, hi1, k1[i]) * a1;
+                const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+                packed |= (uint32_t)(v & 255) << (8 * i);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int sx0 = so[i], sx1 = min(sx0 + 1, S.w - 1);
+                const int a0 = (int)(co[i] & 0xFFFFu), a1 = (int)(co[i] >> 16);
+                const int t0 = r0[sx0] * a0 + r0[sx1] * a1;
+                const int t1 = r1[sx0] * a0 + r1[sx1] * a1;
+                const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+                packed |= (uint32_t)(v & 255) << (8 * i);
+            }
         }
+        *reinterpret_cast<uint32_t*>(dst + (long long)y * D.pitch + x4) = packed;   // pitch padding absorbs the tail
     }
-    *reinterpret_cast<uint32_t*>(dst + (long long)y * D.pitch + x4) = packed;   // pitch padding absorbs the tail
 }
 
 // Copies n_frames images (row_stride / frame_stride) into level 0 of each pyramid slab,
@@ -436,7 +458,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
 // split from the back until the list holds N nodes.  The per-node winner is the key with
 // the highest response, the earliest in emission order among equals.
 // ======================================================================================
-constexpr int kQtThreads = 512;
+constexpr int kQtThreads = 256;
 
 struct QtBox { short ulx, uly, brx, bry; };
 
@@ -760,7 +782,7 @@ __global__ __launch_bounds__(kLayThreads) void k_layout(const OrbxFrameGeo* __re
 //   256 steered comparisons -> 32 bytes
 // ======================================================================================
 constexpr int kDescWaves = 4;
-constexpr int kRawR = 21, kRawW = 43, kRawP = 48;   // raw rows start at a 4-byte aligned column
+constexpr int kRawR = 21, kRawW = 43, kRawP = 64;   // raw rows start at a 16-byte aligned column
 constexpr int kBlurR = 18, kBlurW = 37, kBlurP = 40;
 
 __device__ __forceinline__ int reflect101_dev(int p, int n) {
@@ -864,20 +886,20 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     uint8_t* blur = rawBase;   // the raw patch is dead once the horizontal pass is done
 
     // Patch rows cy-21 .. cy+21, columns cx-21 .. cx+21.  Interior keypoints fetch each row as
-    // 12 aligned dwords starting at the 4-byte aligned column xa <= cx-21 (ox = offset of the
-    // patch inside the tile); keypoints whose patch crosses the level edge take the byte
-    // path with REFLECT_101 indices.
+    // four aligned 16-byte loads starting at the 16-byte aligned column xa <= cx-21 (ox = offset
+    // of the patch inside the tile row); keypoints whose patch crosses the level edge take the
+    // byte path with REFLECT_101 indices.
     const int px0 = cx - kRawR, py0 = cy - kRawR;
-    const int xa = px0 & ~3;
+    const int xa = px0 & ~15;
     const bool interior = px0 >= 0 && py0 >= 0 && cx + kRawR < G.w && cy + kRawR < G.h && xa + kRawP <= G.pitch;
     const int ox = interior ? px0 - xa : 0;
     const uint8_t* raw = rawBase + ox;
     if (active) {
         if (interior) {
-            for (int i = lane; i < kRawW * (kRawP / 4); i += 64) {
-                const int r = i / (kRawP / 4), d = i - r * (kRawP / 4);
-                *reinterpret_cast<uint32_t*>(rawBase + r * kRawP + 4 * d) =
-                    *reinterpret_cast<const uint32_t*>(img + (long long)(py0 + r) * G.pitch + xa + 4 * d);
+            for (int i = lane; i < kRawW * (kRawP / 16); i += 64) {
+                const int r = i >> 2, d = i & 3;
+                *reinterpret_cast<uint4*>(rawBase + r * kRawP + 16 * d) =
+                    *reinterpret_cast<const uint4*>(img + (long long)(py0 + r) * G.pitch + xa + 16 * d);
             }
         } else {
             for (int i = lane; i < kRawW * kRawW; i += 64) {
@@ -894,7 +916,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     for (int i = lane; i < 31 * 31; i += 64) {
         const int v = i / 31 - 15, u = i % 31 - 15;
         const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-        if (au <= c_umax[av]) {
+        // umax[|v|] = 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3, four bits per entry
+        if (au <= (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15ull)) {
             const int p = raw[(kRawR + v) * kRawP + kRawR + u];
             m10 += u * p;
             m01 += v * p;
@@ -907,34 +930,57 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-    // ---- separable 7-tap blur of the 37x37 core, 8 outputs per work item ----
-    // horizontal: item = (raw row r, 8 output columns c0..c0+7) reads 14 bytes once
+    // ---- separable 7-tap blur of the 37x37 core with the dot-product instructions ----
+    // horizontal: item = (raw row r, 8 output columns c0..c0+7).  The 14 source bytes are
+    // fetched as 5 aligned dwords and shifted into a 16-byte window (the patch starts `ox`
+    // bytes into the row); every output is two v_dot4_u32_u8 over byte windows of it.
+    // The row sums are stored TRANSPOSED (horT[c][r]) so that the vertical pass reads
+    // consecutive rows as packed 16-bit pairs.
+    constexpr int kHorTP = 44;                       // rows per column of horT (even)
+    const uint32_t wLo = 18u | (34u << 8) | (48u << 16) | (56u << 24);
+    const uint32_t wHi = 48u | (34u << 8) | (18u << 16);
     for (int i = lane; active && i < kRawW * 5; i += 64) {
         const int r = i / 5, c0 = (i - r * 5) * 8;
-        const uint8_t* p = raw + r * kRawP + c0;
-        int v[14];
+        const int b0 = ox + c0;
+        const uint32_t* rowp = reinterpret_cast<const uint32_t*>(rawBase + r * kRawP) + (b0 >> 2);
+        const uint32_t d0 = rowp[0], d1 = rowp[1], d2 = rowp[2], d3 = rowp[3], d4 = rowp[4];
+        const int sh = b0 & 3;
+        uint32_t W[4];
+        W[0] = __builtin_amdgcn_alignbyte(d1, d0, sh); W[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        W[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); W[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
 #pragma unroll
-        for (int k = 0; k < 14; ++k) v[k] = (c0 + k < kRawW) ? p[k] : 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (c0 + k < kBlurW)
-                hor[r * kBlurP + c0 + k] = (uint16_t)(18 * (v[k] + v[k + 6]) + 34 * (v[k + 1] + v[k + 5]) +
-                                                      48 * (v[k + 2] + v[k + 4]) + 56 * v[k + 3]);
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t lo4 = (k & 3) ? __builtin_amdgcn_alignbyte(W[(k >> 2) + 1], W[k >> 2], k & 3) : W[k >> 2];
+            const uint32_t hi4 = (k & 3) ? __builtin_amdgcn_alignbyte(W[(k >> 2) + 2 > 3 ? 3 : (k >> 2) + 2], W[(k >> 2) + 1], k & 3)
+                                         : W[(k >> 2) + 1];
+            const uint32_t h = __builtin_amdgcn_udot4(hi4, wHi, __builtin_amdgcn_udot4(lo4, wLo, 0u, false), false);
+            if (c0 + k < kBlurW) hor[(c0 + k) * kHorTP + r] = (uint16_t)h;
+        }
     }
     __syncthreads();
-    // vertical: item = (column c, 8 output rows r0..r0+7) reads 14 row sums once
+    // vertical: item = (column c, 8 output rows r0..r0+7): 14 row sums = 7 packed pairs, four
+    // v_dot2_u32_u16 per output; odd rows use the weight pairs shifted by one tap.
     for (int i = lane; active && i < kBlurW * 5; i += 64) {
         const int seg = i / kBlurW, c = i - seg * kBlurW, r0 = seg * 8;
-        const uint16_t* p = hor + r0 * kBlurP + c;
-        uint32_t v[14];
+        const uint32_t* colp = reinterpret_cast<const uint32_t*>(hor + c * kHorTP + r0);
+        us2 Hh[7];
 #pragma unroll
-        for (int k = 0; k < 14; ++k) v[k] = (r0 + k < kRawW) ? p[k * kBlurP] : 0u;
+        for (int m = 0; m < 7; ++m) Hh[m] = __builtin_bit_cast(us2, colp[m]);
+        const us2 e0 = {18, 34}, e1 = {48, 56}, e2 = {48, 34}, e3 = {18, 0};      // even rows: taps 0..6 from the pair start
+        const us2 o0 = {0, 18}, o1 = {34, 48}, o2 = {56, 48}, o3 = {34, 18};      // odd rows: one tap later
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (r0 + k < kBlurW) {
-                const uint32_t sum = 18u * (v[k] + v[k + 6]) + 34u * (v[k + 1] + v[k + 5]) + 48u * (v[k + 2] + v[k + 4]) + 56u * v[k + 3];
-                blur[(r0 + k) * kBlurP + c] = (uint8_t)((sum + 32768u) >> 16);
+        for (int k = 0; k < 8; ++k) {
+            const int j = k >> 1;
+            uint32_t sum = 32768u;
+            if (k & 1) {
+                sum = __builtin_amdgcn_udot2(Hh[j], o0, sum, false);     sum = __builtin_amdgcn_udot2(Hh[j + 1], o1, sum, false);
+                sum = __builtin_amdgcn_udot2(Hh[j + 2], o2, sum, false); sum = __builtin_amdgcn_udot2(Hh[j + 3], o3, sum, false);
+            } else {
+                sum = __builtin_amdgcn_udot2(Hh[j], e0, sum, false);     sum = __builtin_amdgcn_udot2(Hh[j + 1], e1, sum, false);
+                sum = __builtin_amdgcn_udot2(Hh[j + 2], e2, sum, false); sum = __builtin_amdgcn_udot2(Hh[j + 3], e3, sum, false);
             }
+            if (r0 + k < kBlurW) blur[(r0 + k) * kBlurP + c] = (uint8_t)(sum >> 16);
+        }
     }
     __syncthreads();
 
@@ -943,14 +989,17 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     const float deg2rad = (float)(3.14159265358979323846 / 180.f);
     float a, b;
     sincos_f32(__fmul_rn(angle, deg2rad), &b, &a);
+    // the lane's 8 sample points = 16 consecutive signed bytes of the pattern table
+    const uint4 pat4 = *reinterpret_cast<const uint4*>(c_pattern + 16 * lane);
+    const uint32_t pat[4] = {pat4.x, pat4.y, pat4.z, pat4.w};
     uint32_t nib = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         int t[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int pi = ((lane * 4 + j) * 2 + e) * 2;
-            const float px = (float)c_pattern[pi], py = (float)c_pattern[pi + 1];
+            const uint32_t w = pat[j] >> (16 * e);
+            const float px = (float)(int)(signed char)(w & 255u), py = (float)(int)(signed char)((w >> 8) & 255u);
             const int ry = __float2int_rn(__fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a)));
             const int rx = __float2int_rn(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b)));
             t[e] = blur[(kBlurR + ry) * kBlurP + kBlurR + rx];
@@ -1285,8 +1334,11 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
     if (ex->timing && ex->evUsed + kTimedStages + 1 > 4096 * (size_t)(kTimedStages + 1)) resolve_timing(ex);
     mark(ex, st);   // end of copy-in (its start is marked by the caller)
     for (int l = 1; l < nl; ++l) {
-        dim3 grid((g.lv[l].w + 4 * 256 - 1) / (4 * 256), g.lv[l].h, nf);
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, ex->d_geo, l, ex->d_pyr, g.pyrBytes, ex->d_xofs, ex->d_xcoef,
+        // a row needs w/4 lanes: size the workgroup to the row (whole waves, at most 256 lanes)
+        const int lanes = (g.lv[l].w + 3) / 4;
+        const int bs = std::min(256, ((lanes + 63) / 64) * 64);
+        dim3 grid((lanes + bs - 1) / bs, (g.lv[l].h + kResizeRows - 1) / kResizeRows, nf);
+        hipLaunchKernelGGL(k_resize, grid, dim3(bs), 0, st, ex->d_geo, l, ex->d_pyr, g.pyrBytes, ex->d_xofs, ex->d_xcoef,
                            ex->d_yofs, ex->d_ycoef);
     }
     mark(ex, st);
