@@ -58,6 +58,7 @@ PROTOTYPES = {
                                             C.POINTER(C.c_int), C.POINTER(C.c_ssize_t)]),
     "orbx_debug_level_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                               C.POINTER(C.c_int)]),
+    "orbx_debug_wave_sort": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "orbx_debug_level_keypoints": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "orbx_descriptor_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "orbx_hamming_knn2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -23,7 +23,7 @@
 #include <vector>
 
 #include "orbx_common.h"
-#include "orbx_introsort.h"
+#include "orbx_wavesort.h"
 
 // ======================================================================================
 // error string
@@ -592,22 +592,41 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
             for (int p = tid; p < size; p += kQtThreads) base[p] = (cnt[p] > 1) ? scanv[p] : -1;
             __syncthreads();
         } else {
-            // careful pass: sort the expandable record, split from the back until N nodes
+            // careful pass: sort the expandable record, split from the back until N nodes.
+            // Wave 0 does both; scanv / base / nbox are free at this point and serve as its scratch.
+            if (tid < 64) orbx_sort::wave_sort(sortbuf, s_nE, s_sortStack, scanv, base,
+                                               reinterpret_cast<orbx_sort::elem_t*>(nbox));
+            __syncthreads();
             for (int p = tid; p < size; p += kQtThreads) base[p] = -1;
             __syncthreads();
-            if (tid == 0) {
+            if (tid < 64) {
                 const int nE = s_nE;
-                orbx_sort::sort(sortbuf, nE, s_sortStack);
                 int sz = size, seq = 0;
-                for (int j = nE - 1; j >= 0; --j) {
-                    const int p = (int)orbx_sort::payload_of(sortbuf[j]);
-                    const int nc = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0);
-                    base[p] = seq;
-                    seq += nc;
-                    sz += nc - 1;
-                    if (sz >= N) break;
+                bool stop = false;
+                for (int j0 = nE - 1; j0 >= 0 && !stop; j0 -= 64) {
+                    const int j = j0 - tid;
+                    int p = 0, nc = 0;
+                    if (j >= 0) {
+                        p = (int)orbx_sort::payload_of(sortbuf[j]);
+                        nc = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0);
+                    }
+                    int incl = nc;   // inclusive scan over the lanes (lane 0 = back of the record)
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int o = __shfl_up(incl, off, 64);
+                        if (tid >= off) incl += o;
+                    }
+                    // list size after splitting the nodes of lanes 0..tid
+                    const int szAfter = sz + incl - (tid + 1);
+                    const unsigned long long hit = __ballot(j >= 0 && szAfter >= N);
+                    const int lastLane = hit ? (__ffsll((long long)hit) - 1) : min(63, j0);
+                    if (tid <= lastLane) base[p] = seq + incl - nc;
+                    const int chunkSeq = __shfl(incl, lastLane, 64);
+                    seq += chunkSeq;
+                    sz += chunkSeq - (lastLane + 1);
+                    stop = hit != 0ull;
                 }
-                s_total = seq;
+                if (tid == 0) s_total = seq;
             }
             __syncthreads();
             total = s_total;
@@ -664,20 +683,29 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
             bool done = (newSize >= N) || (newSize == size);
             bool toCareful = careful != 0;
             if (!done && !careful && newSize + 3 * nExp > N) toCareful = true;
-            if (!done && toCareful) {
-                // expandable record in creation order = new positions total-1 .. 0
-                int nE = 0;
-                for (int np = total - 1; np >= 0; --np)
-                    if (cnt[np] > 1)
-                        sortbuf[nE++] = orbx_sort::make_elem((uint32_t)cnt[np], (uint32_t)box[np].ulx, (uint32_t)np);
-                s_nE = nE;
-            }
             s_careful = toCareful ? 1 : 0;
             s_done = done ? 1 : 0;
             s_size = newSize;
         }
         __syncthreads();
         careful = s_careful;
+        if (!s_done && careful) {
+            // expandable record in creation order = new positions total-1 .. 0 (compacted by wave 0)
+            if (tid < 64) {
+                int nE = 0;
+                for (int np0 = total - 1; np0 >= 0; np0 -= 64) {
+                    const int np = np0 - tid;
+                    const bool exp = np >= 0 && cnt[np] > 1;
+                    const unsigned long long b = __ballot(exp);
+                    if (exp)
+                        sortbuf[nE + __popcll(b & ((1ull << tid) - 1ull))] =
+                            orbx_sort::make_elem((uint32_t)cnt[np], (uint32_t)box[np].ulx, (uint32_t)np);
+                    nE += __popcll(b);
+                }
+                if (tid == 0) s_nE = nE;
+            }
+            __syncthreads();
+        }
     }
     __syncthreads();
 
@@ -1595,5 +1623,53 @@ extern "C" orbx_status orbx_debug_level_keypoints(orbx_extractor* ex, int frame,
     std::vector<OrbxLevelKp> k(n);
     if (n) ORBX_HIP_TRY(hipMemcpy(k.data(), ex->d_levelKps + (size_t)frame * ex->geo.kpTotal + L.kpOff, n * sizeof(OrbxLevelKp), hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) { xyr[3 * i] = k[i].x; xyr[3 * i + 1] = k[i].y; xyr[3 * i + 2] = k[i].response; }
+    return ORBX_OK;
+}
+
+// ---- stage tap: the one-wave sort on its own -------------------------------------------
+constexpr int kSortTapMax = 2048;
+
+__global__ __launch_bounds__(64) void k_sort_tap(unsigned long long* __restrict__ data, const int* __restrict__ offsets) {
+    extern __shared__ __align__(16) unsigned char st_smem[];
+    const int b = blockIdx.x, n = offsets[b + 1] - offsets[b];
+    unsigned long long* v = reinterpret_cast<unsigned long long*>(st_smem);
+    unsigned long long* out = v + kSortTapMax;
+    int* posL = reinterpret_cast<int*>(out + kSortTapMax);
+    int* posR = posL + kSortTapMax;
+    __shared__ int s_stack[3 * orbx_sort::kStackDepth];
+    unsigned long long* g = data + offsets[b];
+    for (int i = threadIdx.x; i < n; i += 64) v[i] = g[i];
+    __syncthreads();
+    orbx_sort::wave_sort(v, n, s_stack, posL, posR, out);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 64) g[i] = v[i];
+}
+
+extern "C" orbx_status orbx_debug_wave_sort(const uint64_t* elems, const int* offsets, int n_arrays,
+                                            uint64_t* device_sorted, uint64_t* host_sorted) {
+    ORBX_REQUIRE(elems && offsets && device_sorted && host_sorted && n_arrays > 0, "bad argument");
+    ORBX_REQUIRE(offsets[0] == 0, "offsets must start at 0");
+    for (int a = 0; a < n_arrays; ++a)
+        ORBX_REQUIRE(offsets[a + 1] >= offsets[a] && offsets[a + 1] - offsets[a] <= kSortTapMax,
+                     "array %d has %d elements (0..%d allowed)", a, offsets[a + 1] - offsets[a], kSortTapMax);
+    const size_t total = (size_t)offsets[n_arrays];
+    int stack[3 * orbx_sort::kStackDepth];
+    for (size_t i = 0; i < total; ++i) host_sorted[i] = elems[i];
+    for (int a = 0; a < n_arrays; ++a)
+        orbx_sort::sort(reinterpret_cast<orbx_sort::elem_t*>(host_sorted) + offsets[a], offsets[a + 1] - offsets[a], stack);
+    unsigned long long* d_data = nullptr;
+    int* d_off = nullptr;
+    ORBX_HIP_TRY(hipMalloc(&d_data, std::max<size_t>(total, 1) * 8));
+    ORBX_HIP_TRY(hipMalloc(&d_off, (n_arrays + 1) * sizeof(int)));
+    hipError_t e = hipMemcpy(d_data, elems, total * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_off, offsets, (n_arrays + 1) * sizeof(int), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_sort_tap, dim3(n_arrays), dim3(64), kSortTapMax * 24, 0, d_data, d_off);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(device_sorted, d_data, total * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_data);
+    (void)hipFree(d_off);
+    if (e != hipSuccess) { orbx_set_error("orbx_debug_wave_sort: %s", hipGetErrorString(e)); return ORBX_ERR_HIP; }
     return ORBX_OK;
 }

@@ -202,3 +202,44 @@ def test_candidate_buffer_regrows(oracle):
     o = oracle.Extractor(1000)
     g = A.ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480)
     _same(*o(img, (0, 0)), *g(img, (0, 0)))
+
+
+def test_wave_sort_equals_sequential_introsort():
+    """The one-wave device sort must return the permutation of the sequential restatement of
+    libstdc++'s std::sort (which tests/test_introsort.py pins to std::sort itself), ties included."""
+    import ctypes as C
+    A = _gpu()
+    rng = np.random.default_rng(11)
+    arrays = []
+    for n in list(range(0, 70)) + [100, 127, 128, 129, 255, 500, 777, 1000, 1500, 2047, 2048]:
+        for mode in range(7):
+            i = np.arange(n, dtype=np.uint64)
+            if mode == 0:
+                cnt, ulx = 2 + rng.integers(0, 2, n), 16 * rng.integers(0, 4, n)          # heavy ties
+            elif mode == 1:
+                cnt, ulx = 2 + rng.integers(0, 6, n), rng.integers(0, 40, n)
+            elif mode == 2:
+                cnt, ulx = 2 + rng.integers(0, 50, n), rng.integers(0, 700, n)
+            elif mode == 3:
+                cnt, ulx = i.copy(), np.zeros(n)                                          # sorted
+            elif mode == 4:
+                cnt, ulx = n - i, np.zeros(n)                                             # reversed
+            elif mode == 5:
+                cnt, ulx = np.where(i < n // 2, i, n - i), np.full(n, 3)                  # organ pipe
+            else:
+                cnt, ulx = np.full(n, 2), np.zeros(n)                                     # all equal
+            e = (cnt.astype(np.uint64) << np.uint64(40)) | (ulx.astype(np.uint64) << np.uint64(24)) | i
+            arrays.append(e.astype(np.uint64))
+    off = np.zeros(len(arrays) + 1, np.int32)
+    off[1:] = np.cumsum([len(a) for a in arrays])
+    data = np.ascontiguousarray(np.concatenate(arrays))
+    dev, host = np.zeros_like(data), np.zeros_like(data)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    assert A.lib().orbx_debug_wave_sort(p(data), p(off), len(arrays), p(dev), p(host)) == 0
+    bad = [k for k in range(len(arrays)) if not np.array_equal(dev[off[k]:off[k + 1]], host[off[k]:off[k + 1]])]
+    assert not bad, f"{len(bad)} arrays differ, first: n={len(arrays[bad[0]])} index {bad[0]}"
+    # and it is a sort of the input
+    for k in (5, 200, len(arrays) - 1):
+        s = dev[off[k]:off[k + 1]]
+        assert np.array_equal(np.sort(s), np.sort(arrays[k]))
+        assert np.all(np.diff((s >> np.uint64(24)).astype(np.int64)) >= 0)
