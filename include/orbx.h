@@ -242,6 +242,122 @@ orbx_status orbx_bucket_best(const uint8_t* desc1, int n_desc1, const int* idx1,
                              const uint8_t* desc2, int n_desc2, const int* idx2, const int* off2, int n_buckets,
                              int* best_idx2, int* best_dist);
 
+/* ---- order-dependent matcher loops: device candidate lists + in-order replay ----------
+ * The reference's matchers are loops whose iterations depend on each other (a keypoint that
+ * received a map point is skipped by later queries).  Each function below evaluates every
+ * window test, stateless gate and Hamming distance on the device and replays the loop of the
+ * cited reference function on the host, in its order, over the resulting short lists.  The
+ * caller supplies what the reference computes from its object graph before the loop: the
+ * projections, predicted levels and radii as orbx_query records, the map points' descriptors,
+ * and the "skip" flags.  Host pointers; synchronous. */
+
+/* Best-only windowed search.  For every query in order: the closest candidate (strict <,
+ * first seen wins ties) among those with taken[idx] == 0; accepted when dist <= max_dist.
+ * An accepted keypoint gets taken[idx] = query_marks[q] (1 when query_marks == NULL; pass 0
+ * for a map point without observations, which the reference does not treat as occupying the
+ * keypoint, ORBmatcher.cc:1832-1834).  taken == NULL: stateless.  With query_angle != NULL the
+ * rotation-consistency histogram (30 bins, bin = round(rot * rot_factor), 3 dominant bins with
+ * the 10 % rule, ORBmatcher.cc:2096-2137) prunes the matches afterwards.
+ *   kp_match[n_kps]  query that owns each keypoint at the end (-1 none)
+ *   match_out[q]     keypoint of query q if it still owns it, else -1
+ *   *n_matches       the reference's return value (counts overwritten assignments too)
+ * This is the loop of
+ *   SearchByProjection(Frame&, const Frame&, th, bMono)          ORBmatcher.cc:1761-1972  max_dist 100, factor 1/30
+ *   SearchByProjection(Frame&, KeyFrame*, sFound, th, ORBdist)   :1974-2094               max_dist ORBdist, factor 1/30
+ *   SearchByProjection(KeyFrame*, Sim3, points, matched, th, r)  :476-580, :582-693        max_dist 50 * r, no angles
+ *   Fuse(KeyFrame*, Sim3, points, th, replace)                   :1409-1524               taken NULL, max_dist 50
+ * for the mono / rectified camera (Nleft == -1). */
+orbx_status orbx_search_window_best(const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps,
+                                    float min_x, float max_x, float min_y, float max_y,
+                                    const orbx_query* queries, const uint8_t* query_desc, int n_query,
+                                    float max_dist, uint8_t* taken, const uint8_t* query_marks,
+                                    const float* query_angle, float rot_factor,
+                                    int* match_out, int* kp_match, int* n_matches);
+
+/* Fuse(KeyFrame*, const vector<MapPoint*>&, th, bRight) (ORBmatcher.cc:1214-1407), matching
+ * part: per projected map point {x, y, xr = projected right u, radius, pred-1, pred} the closest
+ * keypoint that passes the reprojection gate e2 * inv_level_sigma2[octave] <= 7.8 (keypoint with
+ * uright >= 0, e2 includes the right coordinate) or <= 5.99; accepted when dist <= 50.
+ * match_out[q] = keypoint or -1; what happens to the map (Replace / AddObservation) stays with
+ * the caller. */
+orbx_status orbx_fuse_search(const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps,
+                             float min_x, float max_x, float min_y, float max_y,
+                             const orbx_query* queries, const uint8_t* query_desc, int n_query,
+                             const float* inv_level_sigma2, int n_levels, int* match_out, int* n_matches);
+
+/* SearchBySim3 (ORBmatcher.cc:1526-1743): the map points of keyframe 1 searched in keyframe 2
+ * (queries_into2[q] belongs to keypoint source1[q] of keyframe 1) and vice versa, best-only,
+ * accepted when dist <= 100, then mutual agreement.  bounds = {min_x, max_x, min_y, max_y} of
+ * each keyframe's grid.  matches12[n1] = keypoint of keyframe 2 or -1. */
+orbx_status orbx_search_by_sim3(const orbx_keypoint* kps1, const uint8_t* desc1, int n1, const float bounds1[4],
+                                const orbx_keypoint* kps2, const uint8_t* desc2, int n2, const float bounds2[4],
+                                const orbx_query* queries_into2, const uint8_t* query_desc_into2, const int* source1, int nq1,
+                                const orbx_query* queries_into1, const uint8_t* query_desc_into1, const int* source2, int nq2,
+                                int* matches12, int* n_found);
+
+/* SearchForInitialization (ORBmatcher.cc:695-808): level-0 keypoints of frame 1 searched in
+ * frame 2 inside window_size around prev_matched[i1] ({x, y} pairs, updated on return), best /
+ * second best with the per-keypoint matched-distance rule (:734), accepted when best <= 50 and
+ * best < second * nn_ratio, re-assignment of keypoints of frame 2 (:753-760), rotation histogram
+ * with factor 1/30.  matches12[n1] = keypoint of frame 2 or -1. */
+orbx_status orbx_search_for_initialization(const orbx_keypoint* kps1, const uint8_t* desc1, int n1,
+                                           const orbx_keypoint* kps2, const uint8_t* desc2, int n2,
+                                           float min_x, float max_x, float min_y, float max_y,
+                                           float* prev_matched, int window_size, float nn_ratio, int check_orientation,
+                                           int* matches12, int* n_matches);
+
+/* All Hamming distances between the entries of the same vocabulary node of two feature vectors
+ * (the inner loops of SearchByBoW / SearchForTriangulation, ORBmatcher.cc:273-363, :856-907,
+ * :1030-1078).  Buckets are CSR: entries off[b] .. off[b+1] of idx1 / idx2 are descriptor rows.
+ * Row e (one per idx1 entry) = distances to the idx2 entries of its bucket in bucket order:
+ * dist[row_start[e] + j]; row_start has off1[n_buckets] + 1 entries. */
+orbx_status orbx_bucket_allpairs(const uint8_t* desc1, int n_desc1, const int* idx1, const int* off1,
+                                 const uint8_t* desc2, int n_desc2, const int* idx2, const int* off2, int n_buckets,
+                                 int* row_start, uint16_t* dist, size_t capacity, size_t* n_pairs_out);
+
+/* SearchByBoW(KeyFrame*, Frame&, matches) (ORBmatcher.cc:235-474).  valid_kf[i] != 0: keypoint i
+ * of the keyframe has a map point that is not bad.  n_left_f = Frame::Nleft (-1: one camera;
+ * otherwise frame keypoints >= n_left_f form the right-camera track, whose ratio test the
+ * reference disables, :404).  Accept: best <= 50 and best < nn_ratio * second; rotation
+ * histogram with this fork's factor 30/360 (:255).  match_f[n_f] = keyframe keypoint whose map
+ * point the frame keypoint receives, or -1. */
+orbx_status orbx_search_by_bow(const uint8_t* desc_kf, const float* angle_kf, const uint8_t* valid_kf, int n_kf,
+                               const int* idx_kf, const int* off_kf,
+                               const uint8_t* desc_f, const float* angle_f, int n_f, int n_left_f,
+                               const int* idx_f, const int* off_f, int n_buckets,
+                               float nn_ratio, int check_orientation, int* match_f, int* n_matches);
+
+/* SearchByBoW(KeyFrame*, KeyFrame*, matches12) (ORBmatcher.cc:824-966): valid1 / valid2 mark the
+ * keypoints with a good map point; a keypoint of keyframe 2 is used once; accept: best < 50
+ * (strict) and the ratio test; rotation histogram with factor 1/30.  matches12[n1] = keypoint of
+ * keyframe 2 or -1. */
+orbx_status orbx_search_by_bow_keyframes(const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
+                                         const int* idx1, const int* off1,
+                                         const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
+                                         const int* idx2, const int* off2, int n_buckets,
+                                         float nn_ratio, int check_orientation, int* matches12, int* n_matches);
+
+/* SearchForTriangulation (ORBmatcher.cc:968-1212) for pinhole cameras without a second camera
+ * model.  free1 / free2 != 0: the keypoint has no map point yet; uright (may be NULL) >= 0 marks
+ * stereo keypoints.  Per candidate, in bucket order: dist <= 50 and <= running best, then the
+ * epipole-distance gate (:1089-1097), then (unless coarse) Pinhole::epipolarConstrain
+ * (Pinhole.cpp:118-141) with the caller's F12 (row-major 3x3, = K1^-T [t12]x R12 K2^-1); a later
+ * candidate with an equal distance replaces an earlier one.  Rotation histogram (factor 1/30)
+ * when check_orientation.  matches12[n1] = keypoint of keyframe 2 or -1. */
+typedef struct orbx_epipolar {
+    float F12[9];
+    float epipole_x, epipole_y;        /* projection of camera centre 1 into image 2 */
+    const float* scale_factors2;       /* mvScaleFactors of keyframe 2 */
+    const float* level_sigma2_2;       /* mvLevelSigma2 of keyframe 2 */
+    int n_levels;
+} orbx_epipolar;
+orbx_status orbx_search_for_triangulation(const orbx_keypoint* kps1, const uint8_t* desc1, const uint8_t* free1,
+                                          const float* uright1, int n1, const int* idx1, const int* off1,
+                                          const orbx_keypoint* kps2, const uint8_t* desc2, const uint8_t* free2,
+                                          const float* uright2, int n2, const int* idx2, const int* off2, int n_buckets,
+                                          const orbx_epipolar* geom, int only_stereo, int coarse, int check_orientation,
+                                          int* matches12, int* n_matches);
+
 #ifdef __cplusplus
 }
 #endif

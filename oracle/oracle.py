@@ -77,6 +77,20 @@ def lib():
         L.orc_features_in_area.restype = C.c_int
         L.orc_features_in_area.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int,
                                            C.c_int, C.c_void_p, C.c_int]
+        L.orc_search_window_best.restype = C.c_int
+        L.orc_search_window_best.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 7 + [C.c_int, C.c_float] + [C.c_void_p] * 3 + [C.c_float, C.c_void_p]
+        L.orc_fuse_search.restype = C.c_int
+        L.orc_fuse_search.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_search_by_sim3.restype = C.c_int
+        L.orc_search_by_sim3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + ([C.c_void_p] * 6 + [C.c_int]) * 2 + [C.c_void_p]
+        L.orc_search_for_initialization.restype = C.c_int
+        L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orc_search_by_bow.restype = C.c_int
+        L.orc_search_by_bow.argtypes = [C.c_void_p] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orc_search_by_bow_keyframes.restype = C.c_int
+        L.orc_search_by_bow_keyframes.argtypes = ([C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_void_p]) * 2 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orc_search_for_triangulation.restype = C.c_int
+        L.orc_search_for_triangulation.argtypes = ([C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p]) * 2 + [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_search_by_projection.restype = C.c_int
         L.orc_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -297,3 +311,105 @@ def bucket_best(d1, idx1, off1, d2, idx2, off2):
     bd = np.zeros(len(idx1), np.int32)
     lib().orc_bucket_best(_p(d1), _p(idx1), _p(off1), _p(d2), _p(idx2), _p(off2), len(off1) - 1, _p(bi), _p(bd))
     return bi, bd
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def _u8(a):
+    return None if a is None else np.ascontiguousarray(a, np.uint8)
+
+
+def search_window_best(grid: Grid, fdesc, uRight, qx, qy, qxr, qradius, qmin, qmax, qdesc, max_dist,
+                       taken=None, marks=None, qangle=None, factor=1.0 / 30):
+    """Best-only projection searches; returns (kp_match, taken_after, nmatches)."""
+    fdesc, qdesc = _u8(fdesc), _u8(qdesc)
+    qx, qy, qxr, qradius = _f32(qx), _f32(qy), _f32(qxr), _f32(qradius)
+    qmin, qmax = _i32(qmin), _i32(qmax)
+    uR = None if uRight is None else _f32(uRight)
+    tk = None if taken is None else _u8(taken).copy()
+    mk = _u8(marks)
+    qa = None if qangle is None else _f32(qangle)
+    kpm = np.zeros(len(grid.kps), np.int32)
+    n = lib().orc_search_window_best(grid.g, _p(grid.kps), _p(fdesc), _p(uR), len(grid.kps), _p(qx), _p(qy), _p(qxr),
+                                     _p(qradius), _p(qmin), _p(qmax), _p(qdesc), len(qx), max_dist, _p(tk), _p(mk),
+                                     _p(qa), factor, _p(kpm))
+    return kpm, tk, n
+
+
+def fuse_search(grid: Grid, fdesc, uRight, qu, qv, qur, qradius, qlevel, qdesc, inv_level_sigma2):
+    fdesc, qdesc = _u8(fdesc), _u8(qdesc)
+    qu, qv, qur, qradius = _f32(qu), _f32(qv), _f32(qur), _f32(qradius)
+    qlevel = _i32(qlevel)
+    uR = None if uRight is None else _f32(uRight)
+    sig = _f32(inv_level_sigma2)
+    out = np.zeros(len(qu), np.int32)
+    n = lib().orc_fuse_search(grid.g, _p(grid.kps), _p(fdesc), _p(uR), len(grid.kps), _p(qu), _p(qv), _p(qur),
+                              _p(qradius), _p(qlevel), _p(qdesc), len(qu), _p(sig), _p(out))
+    return out, n
+
+
+def search_by_sim3(grid1: Grid, desc1, grid2: Grid, desc2, into2, into1):
+    """into2 / into1 = (u, v, radius, level, desc, source) of the points of KF1 searched in KF2 and vice versa."""
+    desc1, desc2 = _u8(desc1), _u8(desc2)
+
+    def pack(t):
+        u, v, r, l, d, s = t
+        return [_f32(u), _f32(v), _f32(r), _i32(l), _u8(d), _i32(s)]
+    a, b = pack(into2), pack(into1)
+    out = np.zeros(len(grid1.kps), np.int32)
+    n = lib().orc_search_by_sim3(grid1.g, _p(grid1.kps), _p(desc1), len(grid1.kps), grid2.g, _p(grid2.kps), _p(desc2),
+                                 len(grid2.kps), *[_p(x) for x in a], len(a[0]), *[_p(x) for x in b], len(b[0]), _p(out))
+    return out, n
+
+
+def search_for_initialization(kps1, desc1, grid2: Grid, desc2, prev, window, nnratio, check_ori):
+    kps1 = np.ascontiguousarray(kps1)
+    desc1, desc2 = _u8(desc1), _u8(desc2)
+    prev = _f32(prev).copy()
+    out = np.zeros(len(kps1), np.int32)
+    n = lib().orc_search_for_initialization(_p(kps1), _p(desc1), len(kps1), grid2.g, _p(grid2.kps), _p(desc2),
+                                            len(grid2.kps), _p(prev), window, nnratio, int(check_ori), _p(out))
+    return out, prev, n
+
+
+def search_by_bow(descKF, angleKF, validKF, idxKF, offKF, descF, angleF, n_left, idxF, offF, nnratio, check_ori):
+    descKF, descF = _u8(descKF), _u8(descF)
+    out = np.zeros(len(descF), np.int32)
+    a = [_f32(angleKF), _u8(validKF), _i32(idxKF), _i32(offKF)]
+    b = [_f32(angleF), _i32(idxF), _i32(offF)]
+    n = lib().orc_search_by_bow(_p(descKF), _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(descF), _p(b[0]), len(descF),
+                                n_left, _p(b[1]), _p(b[2]), len(a[3]) - 1, nnratio, int(check_ori), _p(out))
+    return out, n
+
+
+def search_by_bow_keyframes(desc1, angle1, valid1, idx1, off1, desc2, angle2, valid2, idx2, off2, nnratio, check_ori):
+    desc1, desc2 = _u8(desc1), _u8(desc2)
+    a = [_f32(angle1), _u8(valid1), _i32(idx1), _i32(off1)]
+    b = [_f32(angle2), _u8(valid2), _i32(idx2), _i32(off2)]
+    out = np.zeros(len(desc1), np.int32)
+    n = lib().orc_search_by_bow_keyframes(_p(desc1), _p(a[0]), _p(a[1]), len(desc1), _p(a[2]), _p(a[3]),
+                                          _p(desc2), _p(b[0]), _p(b[1]), len(desc2), _p(b[2]), _p(b[3]),
+                                          len(a[3]) - 1, nnratio, int(check_ori), _p(out))
+    return out, n
+
+
+def search_for_triangulation(kps1, desc1, free1, ur1, idx1, off1, kps2, desc2, free2, ur2, idx2, off2,
+                             F12, ep, scale_factors2, level_sigma2_2, only_stereo, coarse, check_ori):
+    kps1, kps2 = np.ascontiguousarray(kps1), np.ascontiguousarray(kps2)
+    desc1, desc2 = _u8(desc1), _u8(desc2)
+    a = [_u8(free1), None if ur1 is None else _f32(ur1), _i32(idx1), _i32(off1)]
+    b = [_u8(free2), None if ur2 is None else _f32(ur2), _i32(idx2), _i32(off2)]
+    F = _f32(F12).reshape(9)
+    sf, sg = _f32(scale_factors2), _f32(level_sigma2_2)
+    out = np.zeros(len(kps1), np.int32)
+    n = lib().orc_search_for_triangulation(_p(kps1), _p(desc1), _p(a[0]), _p(a[1]), len(kps1), _p(a[2]), _p(a[3]),
+                                           _p(kps2), _p(desc2), _p(b[0]), _p(b[1]), len(kps2), _p(b[2]), _p(b[3]),
+                                           len(a[3]) - 1, _p(F), float(ep[0]), float(ep[1]), _p(sf), _p(sg),
+                                           int(only_stereo), int(coarse), int(check_ori), _p(out))
+    return out, n

@@ -978,4 +978,351 @@ void orc_bucket_best(const uint8_t* d1, const int* idx1, const int* off1,
         }
 }
 
+
+// ---- rotation-consistency histogram (ORBmatcher.cc:36, :2096-2137) ----------
+static const int HISTO_LENGTH = 30;
+static void compute_three_maxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+static int rot_bin(float a1, float a2, float factor) {
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)std::round(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+// Best-only projection searches (ORBmatcher.cc:1761-1972, :1974-2094, :476-693, :1409-1524):
+// per query the window candidates in GetFeaturesInArea order, skip occupied keypoints, stereo
+// gate on uRight > 0, strict-< best, accept best <= max_dist, optional rotation pruning.
+// kp_match[idx] = owning query (the reference's mvpMapPoints / vpMatched slot).
+int orc_search_window_best(void* grid, const void* kps_, const uint8_t* fdesc, const float* uRight, int nkp,
+                           const float* qx, const float* qy, const float* qxr, const float* qradius,
+                           const int* qmin, const int* qmax, const uint8_t* qdesc, int nq, float max_dist,
+                           uint8_t* taken, const uint8_t* marks, const float* qangle, float factor, int* kp_match) {
+    const KeyPt* k = (const KeyPt*)kps_;
+    std::vector<int> cand(nkp), rotHist[HISTO_LENGTH];
+    for (int i = 0; i < nkp; ++i) kp_match[i] = -1;
+    int nmatches = 0;
+    for (int q = 0; q < nq; ++q) {
+        const float radius = qradius[q];
+        const int nc = orc_features_in_area(grid, kps_, qx[q], qy[q], radius, qmin[q], qmax[q], cand.data(), nkp);
+        if (nc == 0) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int c = 0; c < nc; ++c) {
+            const int i2 = cand[c];
+            if (taken && taken[i2]) continue;
+            if (uRight && uRight[i2] > 0) {
+                const float er = std::fabs(qxr[q] - uRight[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = hamming256(qdesc + (size_t)q * 32, fdesc + (size_t)i2 * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestIdx2 >= 0 && bestDist <= max_dist) {
+            kp_match[bestIdx2] = q;
+            if (taken) taken[bestIdx2] = marks ? marks[q] : 1;
+            nmatches++;
+            if (qangle) rotHist[rot_bin(qangle[q], k[bestIdx2].angle, factor)].push_back(bestIdx2);
+        }
+    }
+    if (qangle) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (size_t j = 0; j < rotHist[i].size(); j++) { kp_match[rotHist[i][j]] = -1; nmatches--; }
+    }
+    return nmatches;
+}
+
+// Fuse(KeyFrame*, const vector<MapPoint*>&, th, bRight), matching part (ORBmatcher.cc:1315-1382).
+int orc_fuse_search(void* grid, const void* kps_, const uint8_t* fdesc, const float* uRight, int nkp,
+                    const float* qu, const float* qv, const float* qur, const float* qradius, const int* qlevel,
+                    const uint8_t* qdesc, int nq, const float* invLevelSigma2, int* match_out) {
+    const KeyPt* k = (const KeyPt*)kps_;
+    std::vector<int> cand(nkp);
+    int nFused = 0;
+    for (int q = 0; q < nq; ++q) {
+        match_out[q] = -1;
+        const int nPredictedLevel = qlevel[q];
+        const int nc = orc_features_in_area(grid, kps_, qu[q], qv[q], qradius[q], -1, -1, cand.data(), nkp);
+        int bestDist = 256, bestIdx = -1;
+        for (int c = 0; c < nc; ++c) {
+            const int idx = cand[c];
+            const KeyPt& kp = k[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (uRight && uRight[idx] >= 0) {
+                const float ex = qu[q] - kp.x, ey = qv[q] - kp.y, er = qur[q] - uRight[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * invLevelSigma2[kpLevel] > 7.8) continue;
+            } else {
+                const float ex = qu[q] - kp.x, ey = qv[q] - kp.y;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * invLevelSigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = hamming256(qdesc + (size_t)q * 32, fdesc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= 50) { match_out[q] = bestIdx; nFused++; }
+    }
+    return nFused;
+}
+
+// One direction of SearchBySim3 (ORBmatcher.cc:1608-1641): vnMatch[source[q]] = best keypoint.
+static void sim3_direction(void* grid, const KeyPt* k, const uint8_t* fdesc, int nkp, const float* qu, const float* qv,
+                           const float* qradius, const int* qlevel, const uint8_t* qdesc, const int* source, int nq,
+                           std::vector<int>& vnMatch) {
+    std::vector<int> cand(nkp);
+    for (int q = 0; q < nq; ++q) {
+        const int nPredictedLevel = qlevel[q];
+        const int nc = orc_features_in_area(grid, k, qu[q], qv[q], qradius[q], -1, -1, cand.data(), nkp);
+        if (nc == 0) continue;
+        int bestDist = INT_MAX, bestIdx = -1;
+        for (int c = 0; c < nc; ++c) {
+            const int idx = cand[c];
+            if (k[idx].octave < nPredictedLevel - 1 || k[idx].octave > nPredictedLevel) continue;
+            const int dist = hamming256(qdesc + (size_t)q * 32, fdesc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        if (bestDist <= 100) vnMatch[source[q]] = bestIdx;
+    }
+}
+int orc_search_by_sim3(void* grid1, const void* kps1, const uint8_t* desc1, int n1,
+                       void* grid2, const void* kps2, const uint8_t* desc2, int n2,
+                       const float* u12, const float* v12, const float* r12, const int* l12, const uint8_t* d12, const int* src1, int nq1,
+                       const float* u21, const float* v21, const float* r21, const int* l21, const uint8_t* d21, const int* src2, int nq2,
+                       int* matches12) {
+    std::vector<int> vnMatch1(n1, -1), vnMatch2(n2, -1);
+    sim3_direction(grid2, (const KeyPt*)kps2, desc2, n2, u12, v12, r12, l12, d12, src1, nq1, vnMatch1);
+    sim3_direction(grid1, (const KeyPt*)kps1, desc1, n1, u21, v21, r21, l21, d21, src2, nq2, vnMatch2);
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; i1++) {
+        matches12[i1] = -1;
+        int idx2 = vnMatch1[i1];
+        if (idx2 >= 0) {
+            int idx1 = vnMatch2[idx2];
+            if (idx1 == i1) { matches12[i1] = idx2; nFound++; }
+        }
+    }
+    return nFound;
+}
+
+// SearchForInitialization (ORBmatcher.cc:695-808).  prev = vbPrevMatched as {x, y} pairs.
+int orc_search_for_initialization(const void* kps1_, const uint8_t* desc1, int n1, void* grid2, const void* kps2_,
+                                  const uint8_t* desc2, int n2, float* prev, int windowSize, float nnratio,
+                                  int checkOrientation, int* vnMatches12) {
+    const KeyPt* k1 = (const KeyPt*)kps1_;
+    const KeyPt* k2 = (const KeyPt*)kps2_;
+    int nmatches = 0;
+    for (int i = 0; i < n1; ++i) vnMatches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    std::vector<int> vMatchedDistance(n2, INT_MAX), vnMatches21(n2, -1), cand(n2);
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = k1[i1].octave;
+        if (level1 > 0) continue;
+        const int nc = orc_features_in_area(grid2, kps2_, prev[2 * i1], prev[2 * i1 + 1], (float)windowSize, level1, level1, cand.data(), n2);
+        if (nc == 0) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int c = 0; c < nc; ++c) {
+            const int i2 = cand[c];
+            const int dist = hamming256(desc1 + (size_t)i1 * 32, desc2 + (size_t)i2 * 32);
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= 50) {
+            if (bestDist < (float)bestDist2 * nnratio) {
+                if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+                vnMatches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (checkOrientation) rotHist[rot_bin(k1[i1].angle, k2[bestIdx2].angle, factor)].push_back(i1);
+            }
+        }
+    }
+    if (checkOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) {
+                int idx1 = rotHist[i][j];
+                if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)
+        if (vnMatches12[i1] >= 0) { prev[2 * i1] = k2[vnMatches12[i1]].x; prev[2 * i1 + 1] = k2[vnMatches12[i1]].y; }
+    return nmatches;
+}
+
+// SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:235-474).  The two FeatureVectors arrive as
+// CSR over their SHARED nodes (the reference's lower_bound walk visits exactly those).
+int orc_search_by_bow(const uint8_t* descKF, const float* angleKF, const uint8_t* validKF, const int* idxKF, const int* offKF,
+                      const uint8_t* descF, const float* angleF, int nF, int Nleft, const int* idxF, const int* offF,
+                      int nb, float nnratio, int checkOrientation, int* matchF) {
+    for (int i = 0; i < nF; ++i) matchF[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = HISTO_LENGTH / 360.0f;
+    int nmatches = 0;
+    for (int b = 0; b < nb; ++b)
+        for (int iKF = offKF[b]; iKF < offKF[b + 1]; iKF++) {
+            const int realIdxKF = idxKF[iKF];
+            if (!validKF[realIdxKF]) continue;
+            const uint8_t* dKF = descKF + (size_t)realIdxKF * 32;
+            int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256, bestDist1R = 256, bestIdxFR = -1, bestDist2R = 256;
+            for (int iF = offF[b]; iF < offF[b + 1]; iF++) {
+                const int realIdxF = idxF[iF];
+                if (matchF[realIdxF] >= 0) continue;
+                const int dist = hamming256(dKF, descF + (size_t)realIdxF * 32);
+                if (Nleft == -1) {
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                } else {
+                    if (realIdxF < Nleft && dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (realIdxF < Nleft && dist < bestDist2) bestDist2 = dist;
+                    if (realIdxF >= Nleft && dist < bestDist1R) { bestDist2R = bestDist1R; bestDist1R = dist; bestIdxFR = realIdxF; }
+                    else if (realIdxF >= Nleft && dist < bestDist2R) bestDist2R = dist;
+                }
+            }
+            if (bestDist1 <= 50) {
+                if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                    matchF[bestIdxF] = realIdxKF;
+                    if (checkOrientation) rotHist[rot_bin(angleKF[realIdxKF], angleF[bestIdxF], factor)].push_back(bestIdxF);
+                    nmatches++;
+                }
+                if (bestDist1R <= 50) {
+                    matchF[bestIdxFR] = realIdxKF;
+                    if (checkOrientation) rotHist[rot_bin(angleKF[realIdxKF], angleF[bestIdxFR], factor)].push_back(bestIdxFR);
+                    nmatches++;
+                }
+            }
+        }
+    if (checkOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { matchF[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+// SearchByBoW(KeyFrame*, KeyFrame*, ...) (ORBmatcher.cc:824-966).
+int orc_search_by_bow_keyframes(const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1, const int* idx1, const int* off1,
+                                const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2, const int* idx2, const int* off2,
+                                int nb, float nnratio, int checkOrientation, int* matches12) {
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    std::vector<bool> vbMatched2(n2, false);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    for (int b = 0; b < nb; ++b)
+        for (int i1 = off1[b]; i1 < off1[b + 1]; i1++) {
+            const int id1 = idx1[i1];
+            if (!valid1[id1]) continue;
+            int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+            for (int i2 = off2[b]; i2 < off2[b + 1]; i2++) {
+                const int id2 = idx2[i2];
+                if (vbMatched2[id2] || !valid2[id2]) continue;
+                const int dist = hamming256(desc1 + (size_t)id1 * 32, desc2 + (size_t)id2 * 32);
+                if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = id2; }
+                else if (dist < bestDist2) bestDist2 = dist;
+            }
+            if (bestDist1 < 50) {
+                if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                    matches12[id1] = bestIdx2;
+                    vbMatched2[bestIdx2] = true;
+                    if (checkOrientation) rotHist[rot_bin(angle1[id1], angle2[bestIdx2], factor)].push_back(id1);
+                    nmatches++;
+                }
+            }
+        }
+    if (checkOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { matches12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
+// SearchForTriangulation (ORBmatcher.cc:968-1212), pinhole cameras, no second camera model;
+// Pinhole::epipolarConstrain (Pinhole.cpp:118-141) with the fundamental matrix given (row-major).
+int orc_search_for_triangulation(const void* kps1_, const uint8_t* desc1, const uint8_t* free1, const float* uRight1, int n1,
+                                 const int* idx1, const int* off1, const void* kps2_, const uint8_t* desc2,
+                                 const uint8_t* free2, const float* uRight2, int n2, const int* idx2, const int* off2, int nb,
+                                 const float* F12, float epx, float epy, const float* scaleFactors2, const float* levelSigma2_2,
+                                 int bOnlyStereo, int bCoarse, int checkOrientation, int* vMatches12) {
+    const KeyPt* k1 = (const KeyPt*)kps1_;
+    const KeyPt* k2 = (const KeyPt*)kps2_;
+    (void)n2;
+    for (int i = 0; i < n1; ++i) vMatches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    for (int b = 0; b < nb; ++b)
+        for (int i1 = off1[b]; i1 < off1[b + 1]; i1++) {
+            const int id1 = idx1[i1];
+            if (!free1[id1]) continue;
+            const bool bStereo1 = uRight1 && uRight1[id1] >= 0;
+            if (bOnlyStereo && !bStereo1) continue;
+            const KeyPt& kp1 = k1[id1];
+            int bestDist = 50, bestIdx2 = -1;
+            for (int i2 = off2[b]; i2 < off2[b + 1]; i2++) {
+                const int id2 = idx2[i2];
+                if (!free2[id2]) continue;
+                const bool bStereo2 = uRight2 && uRight2[id2] >= 0;
+                if (bOnlyStereo && !bStereo2) continue;
+                const int dist = hamming256(desc1 + (size_t)id1 * 32, desc2 + (size_t)id2 * 32);
+                if (dist > 50 || dist > bestDist) continue;
+                const KeyPt& kp2 = k2[id2];
+                if (!bStereo1 && !bStereo2) {
+                    const float distex = epx - kp2.x, distey = epy - kp2.y;
+                    if (distex * distex + distey * distey < 100 * scaleFactors2[kp2.octave]) continue;
+                }
+                bool ok = bCoarse != 0;
+                if (!ok) {
+                    const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+                    const float bb = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+                    const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+                    const float num = a * kp2.x + bb * kp2.y + c;
+                    const float den = a * a + bb * bb;
+                    if (den == 0) ok = false;
+                    else { const float dsqr = num * num / den; ok = dsqr < 3.84 * levelSigma2_2[kp2.octave]; }
+                }
+                if (ok) { bestIdx2 = id2; bestDist = dist; }
+            }
+            if (bestIdx2 >= 0) {
+                vMatches12[id1] = bestIdx2;
+                nmatches++;
+                if (checkOrientation) rotHist[rot_bin(kp1.angle, k2[bestIdx2].angle, factor)].push_back(id1);
+            }
+        }
+    if (checkOrientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (size_t j = 0; j < rotHist[i].size(); j++) { vMatches12[rotHist[i][j]] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}
+
 }  // extern "C"

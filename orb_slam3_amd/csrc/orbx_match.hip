@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void k_window(OrbxGridDev g, const orbx_keypoi
                                                 const orbx_query* __restrict__ queries, const uint32_t* __restrict__ qdesc,
                                                 int nq, int mode, int* __restrict__ candCount,
                                                 const int* __restrict__ candOffset, int* __restrict__ candIdx,
-                                                int* __restrict__ candDist) {
+                                                int* __restrict__ candDist, const float* __restrict__ invSigma2) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= nq) return;
@@ -562,7 +562,17 @@ __global__ __launch_bounds__(256) void k_window(OrbxGridDev g, const orbx_keypoi
                     }
                     const float dx = __fsub_rn(kp.x, Q.x), dy = __fsub_rn(kp.y, Q.y);
                     if (!(fabsf(dx) < r && fabsf(dy) < r)) ok = false;
-                    if (ok && uright != nullptr) {
+                    if (ok && invSigma2 != nullptr) {
+                        // Fuse: reprojection error against the keypoint, chi-square gates 7.8 (stereo
+                        // keypoint) / 5.99 (ORBmatcher.cc:1341-1365)
+                        const float ur = uright ? uright[idx] : -1.f;
+                        float e2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));   // (u - kpx)^2 == (kpx - u)^2
+                        if (ur >= 0) {
+                            const float er = __fsub_rn(Q.xr, ur);
+                            e2 = __fadd_rn(e2, __fmul_rn(er, er));
+                            if ((double)__fmul_rn(e2, invSigma2[kp.octave]) > 7.8) ok = false;
+                        } else if ((double)__fmul_rn(e2, invSigma2[kp.octave]) > 5.99) ok = false;
+                    } else if (ok && uright != nullptr) {
                         const float ur = uright[idx];
                         if (ur > 0 && fabsf(__fsub_rn(Q.xr, ur)) > r) ok = false;
                     }
@@ -615,7 +625,8 @@ void build_grid(const orbx_keypoint* kps, int n, float minX, float maxX, float m
 static orbx_status window_candidates_impl(const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps,
                                           float min_x, float max_x, float min_y, float max_y, const orbx_query* queries,
                                           const uint8_t* query_desc, int n_query, std::vector<int>& offset,
-                                          std::vector<int>& idx, std::vector<int>& dist) {
+                                          std::vector<int>& idx, std::vector<int>& dist,
+                                          const float* inv_sigma2 = nullptr, int n_levels = 0) {
     ORBX_REQUIRE(n_kps >= 0 && n_query >= 0, "negative size");
     ORBX_REQUIRE(max_x > min_x && max_y > min_y, "empty image bounds");
     offset.assign(n_query + 1, 0);
@@ -630,6 +641,14 @@ static orbx_status window_candidates_impl(const orbx_keypoint* kps, const uint8_
     ORBX_HIP_TRY(dUr.alloc((size_t)n_kps * 4));
     ORBX_HIP_TRY(dQ.alloc((size_t)n_query * sizeof(orbx_query))); ORBX_HIP_TRY(dQd.alloc((size_t)n_query * 32));
     ORBX_HIP_TRY(dCount.alloc((size_t)n_query * 4)); ORBX_HIP_TRY(dOff.alloc((size_t)(n_query + 1) * 4));
+    DevBuf dSig;
+    if (inv_sigma2) {
+        ORBX_REQUIRE(n_levels > 0, "inv_level_sigma2 without levels");
+        for (int i = 0; i < n_kps; ++i)
+            ORBX_REQUIRE(kps[i].octave >= 0 && kps[i].octave < n_levels, "keypoint %d: octave %d outside the %d levels", i, kps[i].octave, n_levels);
+        ORBX_HIP_TRY(dSig.alloc((size_t)n_levels * 4));
+        ORBX_HIP_TRY(hipMemcpy(dSig.p, inv_sigma2, (size_t)n_levels * 4, hipMemcpyHostToDevice));
+    }
     ORBX_HIP_TRY(hipMemcpy(dStart.p, hg.cellStart.data(), hg.cellStart.size() * 4, hipMemcpyHostToDevice));
     if (!hg.cellIdx.empty()) ORBX_HIP_TRY(hipMemcpy(dIdx.p, hg.cellIdx.data(), hg.cellIdx.size() * 4, hipMemcpyHostToDevice));
     ORBX_HIP_TRY(hipMemcpy(dKps.p, kps, (size_t)n_kps * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
@@ -643,7 +662,7 @@ static orbx_status window_candidates_impl(const orbx_keypoint* kps, const uint8_
     const dim3 grid((n_query + 3) / 4), block(256);
     hipLaunchKernelGGL(k_window, grid, block, 0, 0, g, dKps.as<orbx_keypoint>(), dDesc.as<uint32_t>(),
                        uright ? dUr.as<float>() : nullptr, dQ.as<orbx_query>(), dQd.as<uint32_t>(), n_query, 0,
-                       dCount.as<int>(), nullptr, nullptr, nullptr);
+                       dCount.as<int>(), nullptr, nullptr, nullptr, inv_sigma2 ? dSig.as<float>() : nullptr);
     ORBX_HIP_TRY(hipGetLastError());
     std::vector<int> count(n_query);
     ORBX_HIP_TRY(hipMemcpy(count.data(), dCount.p, (size_t)n_query * 4, hipMemcpyDeviceToHost));
@@ -655,7 +674,7 @@ static orbx_status window_candidates_impl(const orbx_keypoint* kps, const uint8_
     ORBX_HIP_TRY(hipMemcpy(dOff.p, offset.data(), (size_t)(n_query + 1) * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_window, grid, block, 0, 0, g, dKps.as<orbx_keypoint>(), dDesc.as<uint32_t>(),
                        uright ? dUr.as<float>() : nullptr, dQ.as<orbx_query>(), dQd.as<uint32_t>(), n_query, 1,
-                       nullptr, dOff.as<int>(), dCi.as<int>(), dCd.as<int>());
+                       nullptr, dOff.as<int>(), dCi.as<int>(), dCd.as<int>(), inv_sigma2 ? dSig.as<float>() : nullptr);
     ORBX_HIP_TRY(hipGetLastError());
     ORBX_HIP_TRY(hipMemcpy(idx.data(), dCi.p, (size_t)total * 4, hipMemcpyDeviceToHost));
     ORBX_HIP_TRY(hipMemcpy(dist.data(), dCd.p, (size_t)total * 4, hipMemcpyDeviceToHost));
@@ -784,5 +803,467 @@ extern "C" orbx_status orbx_bucket_best(const uint8_t* desc1, int n_desc1, const
     ORBX_HIP_TRY(hipGetLastError());
     ORBX_HIP_TRY(hipMemcpy(best_idx2, BI.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
     ORBX_HIP_TRY(hipMemcpy(best_dist, BD.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// ======================================================================================
+// Host-side replay of the matcher loops over the device-built candidate lists.
+// The loops carry state from one query to the next ("this keypoint already has a map
+// point"), so they run in the reference's order on the host; every Hamming distance and
+// every stateless gate was evaluated on the device.
+// ======================================================================================
+namespace {
+constexpr int kHistoLength = 30;   // HISTO_LENGTH (ORBmatcher.cc:36)
+
+// Rotation-consistency histogram (ORBmatcher.cc:1869-1876 and its twins, :2096-2137).
+struct RotHist {
+    std::vector<int> bins[kHistoLength];
+    float factor;
+    explicit RotHist(float f) : factor(f) {}
+    bool add(float angle1, float angle2, int payload) {
+        float rot = angle1 - angle2;
+        if (rot < 0.0) rot += 360.0f;
+        int bin = (int)std::round(rot * factor);
+        if (bin == kHistoLength) bin = 0;
+        if (bin < 0 || bin >= kHistoLength) return false;   // the reference asserts
+        bins[bin].push_back(payload);
+        return true;
+    }
+    // ComputeThreeMaxima
+    void three_maxima(int& ind1, int& ind2, int& ind3) const {
+        int max1 = 0, max2 = 0, max3 = 0;
+        ind1 = ind2 = ind3 = -1;
+        for (int i = 0; i < kHistoLength; ++i) {
+            const int s = (int)bins[i].size();
+            if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+            else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+            else if (s > max3) { max3 = s; ind3 = i; }
+        }
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    }
+    template <class F> void for_each_rejected(F f) const {
+        int i1, i2, i3;
+        three_maxima(i1, i2, i3);
+        for (int i = 0; i < kHistoLength; ++i) {
+            if (i == i1 || i == i2 || i == i3) continue;
+            for (int v : bins[i]) f(v);
+        }
+    }
+};
+}  // namespace
+
+extern "C" orbx_status orbx_search_window_best(const orbx_keypoint* kps, const uint8_t* desc, const float* uright,
+                                               int n_kps, float min_x, float max_x, float min_y, float max_y,
+                                               const orbx_query* queries, const uint8_t* query_desc, int n_query,
+                                               float max_dist, uint8_t* taken, const uint8_t* query_marks,
+                                               const float* query_angle, float rot_factor, int* match_out,
+                                               int* kp_match, int* n_matches) {
+    ORBX_REQUIRE(n_matches && (n_query == 0 || match_out) && (n_kps == 0 || kp_match), "null argument");
+    std::vector<int> off, idx, dist;
+    orbx_status s = window_candidates_impl(kps, desc, uright, n_kps, min_x, max_x, min_y, max_y, queries, query_desc,
+                                           n_query, off, idx, dist);
+    if (s != ORBX_OK) return s;
+    for (int i = 0; i < n_kps; ++i) kp_match[i] = -1;
+    RotHist hist(rot_factor);
+    int nm = 0;
+    for (int q = 0; q < n_query; ++q) {
+        match_out[q] = -1;
+        int best = 256, bestIdx = -1;
+        for (int c = off[q]; c < off[q + 1]; ++c) {
+            const int i = idx[c];
+            if (taken && taken[i]) continue;
+            if (dist[c] < best) { best = dist[c]; bestIdx = i; }
+        }
+        if (bestIdx < 0 || !((float)best <= max_dist)) continue;
+        match_out[q] = bestIdx;
+        kp_match[bestIdx] = q;
+        if (taken) taken[bestIdx] = query_marks ? query_marks[q] : 1;
+        ++nm;
+        if (query_angle)
+            ORBX_REQUIRE(hist.add(query_angle[q], kps[bestIdx].angle, bestIdx), "rotation bin out of range (query %d)", q);
+    }
+    if (query_angle) hist.for_each_rejected([&](int i) { kp_match[i] = -1; --nm; });
+    // a query keeps its keypoint only if it is still the keypoint's owner
+    for (int q = 0; q < n_query; ++q)
+        if (match_out[q] >= 0 && kp_match[match_out[q]] != q) match_out[q] = -1;
+    *n_matches = nm;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_fuse_search(const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps,
+                                        float min_x, float max_x, float min_y, float max_y, const orbx_query* queries,
+                                        const uint8_t* query_desc, int n_query, const float* inv_level_sigma2,
+                                        int n_levels, int* match_out, int* n_matches) {
+    ORBX_REQUIRE(n_matches && (n_query == 0 || match_out) && inv_level_sigma2, "null argument");
+    std::vector<int> off, idx, dist;
+    orbx_status s = window_candidates_impl(kps, desc, uright, n_kps, min_x, max_x, min_y, max_y, queries, query_desc,
+                                           n_query, off, idx, dist, inv_level_sigma2, n_levels);
+    if (s != ORBX_OK) return s;
+    int nm = 0;
+    for (int q = 0; q < n_query; ++q) {
+        int best = 256, bestIdx = -1;
+        for (int c = off[q]; c < off[q + 1]; ++c)
+            if (dist[c] < best) { best = dist[c]; bestIdx = idx[c]; }
+        match_out[q] = (bestIdx >= 0 && best <= 50) ? bestIdx : -1;
+        nm += match_out[q] >= 0;
+    }
+    *n_matches = nm;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_search_by_sim3(const orbx_keypoint* kps1, const uint8_t* desc1, int n1, const float bounds1[4],
+                                           const orbx_keypoint* kps2, const uint8_t* desc2, int n2, const float bounds2[4],
+                                           const orbx_query* queries_into2, const uint8_t* query_desc_into2,
+                                           const int* source1, int nq1, const orbx_query* queries_into1,
+                                           const uint8_t* query_desc_into1, const int* source2, int nq2,
+                                           int* matches12, int* n_found) {
+    ORBX_REQUIRE(bounds1 && bounds2 && n_found && (n1 == 0 || matches12), "null argument");
+    ORBX_REQUIRE((nq1 == 0 || source1) && (nq2 == 0 || source2), "null argument");
+    std::vector<int> vnMatch1(n1, -1), vnMatch2(n2, -1), off, idx, dist;
+    // KF1's points searched in KF2 (ORBmatcher.cc:1565-1642)
+    orbx_status s = window_candidates_impl(kps2, desc2, nullptr, n2, bounds2[0], bounds2[1], bounds2[2], bounds2[3],
+                                           queries_into2, query_desc_into2, nq1, off, idx, dist);
+    if (s != ORBX_OK) return s;
+    for (int q = 0; q < nq1; ++q) {
+        ORBX_REQUIRE(source1[q] >= 0 && source1[q] < n1, "source1[%d] out of range", q);
+        int best = 0x7FFFFFFF, bestIdx = -1;
+        for (int c = off[q]; c < off[q + 1]; ++c)
+            if (dist[c] < best) { best = dist[c]; bestIdx = idx[c]; }
+        if (best <= 100) vnMatch1[source1[q]] = bestIdx;
+    }
+    // KF2's points searched in KF1 (:1645-1722)
+    s = window_candidates_impl(kps1, desc1, nullptr, n1, bounds1[0], bounds1[1], bounds1[2], bounds1[3], queries_into1,
+                               query_desc_into1, nq2, off, idx, dist);
+    if (s != ORBX_OK) return s;
+    for (int q = 0; q < nq2; ++q) {
+        ORBX_REQUIRE(source2[q] >= 0 && source2[q] < n2, "source2[%d] out of range", q);
+        int best = 0x7FFFFFFF, bestIdx = -1;
+        for (int c = off[q]; c < off[q + 1]; ++c)
+            if (dist[c] < best) { best = dist[c]; bestIdx = idx[c]; }
+        if (best <= 100) vnMatch2[source2[q]] = bestIdx;
+    }
+    // agreement (:1725-1740)
+    int nf = 0;
+    for (int i1 = 0; i1 < n1; ++i1) {
+        matches12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0 && vnMatch2[idx2] == i1) { matches12[i1] = idx2; ++nf; }
+    }
+    *n_found = nf;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_search_for_initialization(const orbx_keypoint* kps1, const uint8_t* desc1, int n1,
+                                                      const orbx_keypoint* kps2, const uint8_t* desc2, int n2,
+                                                      float min_x, float max_x, float min_y, float max_y,
+                                                      float* prev_matched, int window_size, float nn_ratio,
+                                                      int check_orientation, int* matches12, int* n_matches) {
+    ORBX_REQUIRE(n_matches && (n1 == 0 || (kps1 && desc1 && prev_matched && matches12)), "null argument");
+    // queries: level-0 keypoints of the first frame around their previous match (ORBmatcher.cc:708-715)
+    std::vector<orbx_query> qs;
+    std::vector<uint8_t> qd;
+    std::vector<int> src;
+    for (int i1 = 0; i1 < n1; ++i1) {
+        matches12[i1] = -1;
+        if (kps1[i1].octave > 0) continue;
+        orbx_query q;
+        q.x = prev_matched[2 * i1]; q.y = prev_matched[2 * i1 + 1]; q.xr = 0.f;
+        q.radius = (float)window_size;
+        q.min_level = 0; q.max_level = 0;
+        qs.push_back(q);
+        qd.insert(qd.end(), desc1 + 32ll * i1, desc1 + 32ll * i1 + 32);
+        src.push_back(i1);
+    }
+    std::vector<int> off, idx, dist;
+    orbx_status s = window_candidates_impl(kps2, desc2, nullptr, n2, min_x, max_x, min_y, max_y, qs.data(), qd.data(),
+                                           (int)qs.size(), off, idx, dist);
+    if (s != ORBX_OK) return s;
+    std::vector<int> matchedDistance(n2, 0x7FFFFFFF), matches21(n2, -1);
+    RotHist hist(1.0f / kHistoLength);
+    int nm = 0;
+    for (int q = 0; q < (int)qs.size(); ++q) {
+        const int i1 = src[q];
+        int best = 0x7FFFFFFF, best2 = 0x7FFFFFFF, bestIdx2 = -1;
+        for (int c = off[q]; c < off[q + 1]; ++c) {
+            const int i2 = idx[c], d = dist[c];
+            if (matchedDistance[i2] <= d) continue;
+            if (d < best) { best2 = best; best = d; bestIdx2 = i2; }
+            else if (d < best2) best2 = d;
+        }
+        if (best <= 50 && (float)best < (float)best2 * nn_ratio) {
+            if (matches21[bestIdx2] >= 0) { matches12[matches21[bestIdx2]] = -1; --nm; }
+            matches12[i1] = bestIdx2;
+            matches21[bestIdx2] = i1;
+            matchedDistance[bestIdx2] = best;
+            ++nm;
+            if (check_orientation)
+                ORBX_REQUIRE(hist.add(kps1[i1].angle, kps2[bestIdx2].angle, i1), "rotation bin out of range (keypoint %d)", i1);
+        }
+    }
+    if (check_orientation)
+        hist.for_each_rejected([&](int i1) { if (matches12[i1] >= 0) { matches12[i1] = -1; --nm; } });
+    for (int i1 = 0; i1 < n1; ++i1)
+        if (matches12[i1] >= 0) { prev_matched[2 * i1] = kps2[matches12[i1]].x; prev_matched[2 * i1 + 1] = kps2[matches12[i1]].y; }
+    *n_matches = nm;
+    return ORBX_OK;
+}
+
+// ======================================================================================
+// Bucketed all-pairs distances (the inner loops of SearchByBoW / SearchForTriangulation)
+// ======================================================================================
+// One wave per idx1 entry; row i of the output holds the distances to the idx2 entries of
+// the same bucket, in bucket order: out[rowStart[i] + j].
+__global__ __launch_bounds__(256) void k_bucket_allpairs(const uint32_t* __restrict__ d1, const int* __restrict__ idx1,
+                                                         const uint32_t* __restrict__ d2, const int* __restrict__ idx2,
+                                                         const int* __restrict__ off2, const int* __restrict__ bucketOf,
+                                                         const int* __restrict__ rowStart, int n1,
+                                                         uint16_t* __restrict__ out) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n1) return;
+    const int b = bucketOf[i];
+    uint32_t a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = d1[8ll * idx1[i] + k];
+    const int jb = off2[b], je = off2[b + 1];
+    uint16_t* row = out + rowStart[i];
+    for (int j = jb + lane; j < je; j += 64) {
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d += __popc(a[k] ^ d2[8ll * idx2[j] + k]);
+        row[j - jb] = (uint16_t)d;
+    }
+}
+
+namespace {
+struct BucketPairs {
+    std::vector<int> bucketOf;     // per idx1 entry
+    std::vector<int> rowStart;     // per idx1 entry (+1)
+    std::vector<uint16_t> dist;    // rows of distances
+};
+}  // namespace
+
+static orbx_status bucket_allpairs_impl(const uint8_t* desc1, int n_desc1, const int* idx1, const int* off1,
+                                        const uint8_t* desc2, int n_desc2, const int* idx2, const int* off2, int n_buckets,
+                                        BucketPairs& bp) {
+    ORBX_REQUIRE(n_buckets >= 0 && n_desc1 >= 0 && n_desc2 >= 0, "negative size");
+    bp.bucketOf.clear(); bp.rowStart.assign(1, 0); bp.dist.clear();
+    if (n_buckets == 0) return ORBX_OK;
+    ORBX_REQUIRE(off1 && off2, "null argument");
+    const int n1 = off1[n_buckets], n2 = off2[n_buckets];
+    ORBX_REQUIRE(off1[0] == 0 && off2[0] == 0, "bucket offsets must start at 0");
+    bp.bucketOf.resize(n1);
+    bp.rowStart.resize(n1 + 1);
+    long long total = 0;
+    for (int b = 0; b < n_buckets; ++b) {
+        ORBX_REQUIRE(off1[b + 1] >= off1[b] && off2[b + 1] >= off2[b], "bad bucket offsets");
+        for (int i = off1[b]; i < off1[b + 1]; ++i) {
+            bp.bucketOf[i] = b;
+            bp.rowStart[i] = (int)total;
+            total += off2[b + 1] - off2[b];
+            ORBX_REQUIRE(total < 0x7FFFFFFF, "too many bucket pairs");
+        }
+    }
+    bp.rowStart[n1] = (int)total;
+    bp.dist.assign((size_t)total, 0);
+    if (n1 == 0 || total == 0) return ORBX_OK;
+    ORBX_REQUIRE(desc1 && idx1 && desc2 && idx2, "null argument");
+    for (int i = 0; i < n1; ++i) ORBX_REQUIRE(idx1[i] >= 0 && idx1[i] < n_desc1, "idx1 out of range");
+    for (int j = 0; j < n2; ++j) ORBX_REQUIRE(idx2[j] >= 0 && idx2[j] < n_desc2, "idx2 out of range");
+    DevBuf D1, D2, I1, I2, O2, BO, RS, OUT;
+    ORBX_HIP_TRY(D1.alloc((size_t)n_desc1 * 32)); ORBX_HIP_TRY(D2.alloc((size_t)n_desc2 * 32));
+    ORBX_HIP_TRY(I1.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(I2.alloc((size_t)n2 * 4));
+    ORBX_HIP_TRY(O2.alloc((size_t)(n_buckets + 1) * 4)); ORBX_HIP_TRY(BO.alloc((size_t)n1 * 4));
+    ORBX_HIP_TRY(RS.alloc((size_t)(n1 + 1) * 4)); ORBX_HIP_TRY(OUT.alloc((size_t)total * 2));
+    ORBX_HIP_TRY(hipMemcpy(D1.p, desc1, (size_t)n_desc1 * 32, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(D2.p, desc2, (size_t)n_desc2 * 32, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(I1.p, idx1, (size_t)n1 * 4, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(I2.p, idx2, (size_t)n2 * 4, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(O2.p, off2, (size_t)(n_buckets + 1) * 4, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(BO.p, bp.bucketOf.data(), (size_t)n1 * 4, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(RS.p, bp.rowStart.data(), (size_t)(n1 + 1) * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_bucket_allpairs, dim3((n1 + 3) / 4), dim3(256), 0, 0, D1.as<uint32_t>(), I1.as<int>(),
+                       D2.as<uint32_t>(), I2.as<int>(), O2.as<int>(), BO.as<int>(), RS.as<int>(), n1, OUT.as<uint16_t>());
+    ORBX_HIP_TRY(hipGetLastError());
+    ORBX_HIP_TRY(hipMemcpy(bp.dist.data(), OUT.p, (size_t)total * 2, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_bucket_allpairs(const uint8_t* desc1, int n_desc1, const int* idx1, const int* off1,
+                                            const uint8_t* desc2, int n_desc2, const int* idx2, const int* off2,
+                                            int n_buckets, int* row_start, uint16_t* dist, size_t capacity,
+                                            size_t* n_pairs_out) {
+    ORBX_REQUIRE(n_pairs_out, "null argument");
+    BucketPairs bp;
+    orbx_status s = bucket_allpairs_impl(desc1, n_desc1, idx1, off1, desc2, n_desc2, idx2, off2, n_buckets, bp);
+    if (s != ORBX_OK) return s;
+    *n_pairs_out = bp.dist.size();
+    if (n_buckets == 0) return ORBX_OK;
+    ORBX_REQUIRE(row_start, "null argument");
+    memcpy(row_start, bp.rowStart.data(), bp.rowStart.size() * sizeof(int));
+    if (bp.dist.size() > capacity) { orbx_set_error("%zu pairs, capacity %zu", bp.dist.size(), capacity); return ORBX_ERR_CAPACITY; }
+    if (!bp.dist.empty()) { ORBX_REQUIRE(dist, "null argument"); memcpy(dist, bp.dist.data(), bp.dist.size() * 2); }
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_search_by_bow(const uint8_t* desc_kf, const float* angle_kf, const uint8_t* valid_kf, int n_kf,
+                                          const int* idx_kf, const int* off_kf, const uint8_t* desc_f,
+                                          const float* angle_f, int n_f, int n_left_f, const int* idx_f, const int* off_f,
+                                          int n_buckets, float nn_ratio, int check_orientation, int* match_f,
+                                          int* n_matches) {
+    ORBX_REQUIRE(n_matches && (n_f == 0 || match_f) && (n_kf == 0 || valid_kf), "null argument");
+    ORBX_REQUIRE(!check_orientation || ((n_kf == 0 || angle_kf) && (n_f == 0 || angle_f)), "orientation check needs the angles");
+    BucketPairs bp;
+    orbx_status s = bucket_allpairs_impl(desc_kf, n_kf, idx_kf, off_kf, desc_f, n_f, idx_f, off_f, n_buckets, bp);
+    if (s != ORBX_OK) return s;
+    for (int i = 0; i < n_f; ++i) match_f[i] = -1;
+    RotHist hist((float)kHistoLength / 360.0f);   // this fork's factor for this function (ORBmatcher.cc:255)
+    int nm = 0;
+    for (int b = 0; b < n_buckets; ++b) {
+        const int jb = off_f[b], je = off_f[b + 1];
+        for (int e = off_kf[b]; e < off_kf[b + 1]; ++e) {
+            const int realIdxKF = idx_kf[e];
+            if (!valid_kf[realIdxKF]) continue;
+            const uint16_t* row = bp.dist.data() + bp.rowStart[e];
+            int best1 = 256, bestIdx = -1, best2 = 256, best1R = 256, bestIdxR = -1, best2R = 256;
+            for (int j = jb; j < je; ++j) {
+                const int realIdxF = idx_f[j];
+                if (match_f[realIdxF] >= 0) continue;
+                const int d = row[j - jb];
+                if (n_left_f == -1 || realIdxF < n_left_f) {
+                    if (d < best1) { best2 = best1; best1 = d; bestIdx = realIdxF; }
+                    else if (d < best2) best2 = d;
+                } else {
+                    if (d < best1R) { best2R = best1R; best1R = d; bestIdxR = realIdxF; }
+                    else if (d < best2R) best2R = d;
+                }
+            }
+            if (best1 <= 50) {
+                if ((float)best1 < nn_ratio * (float)best2) {
+                    match_f[bestIdx] = realIdxKF;
+                    if (check_orientation)
+                        ORBX_REQUIRE(hist.add(angle_kf[realIdxKF], angle_f[bestIdx], bestIdx), "rotation bin out of range");
+                    ++nm;
+                }
+                if (best1R <= 50) {   // right-camera track: the ratio test is disabled in the reference (:404)
+                    match_f[bestIdxR] = realIdxKF;
+                    if (check_orientation)
+                        ORBX_REQUIRE(hist.add(angle_kf[realIdxKF], angle_f[bestIdxR], bestIdxR), "rotation bin out of range");
+                    ++nm;
+                }
+            }
+        }
+    }
+    if (check_orientation) hist.for_each_rejected([&](int i) { match_f[i] = -1; --nm; });
+    *n_matches = nm;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_search_by_bow_keyframes(const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
+                                                    const int* idx1, const int* off1, const uint8_t* desc2,
+                                                    const float* angle2, const uint8_t* valid2, int n2, const int* idx2,
+                                                    const int* off2, int n_buckets, float nn_ratio, int check_orientation,
+                                                    int* matches12, int* n_matches) {
+    ORBX_REQUIRE(n_matches && (n1 == 0 || (matches12 && valid1)) && (n2 == 0 || valid2), "null argument");
+    ORBX_REQUIRE(!check_orientation || ((n1 == 0 || angle1) && (n2 == 0 || angle2)), "orientation check needs the angles");
+    BucketPairs bp;
+    orbx_status s = bucket_allpairs_impl(desc1, n1, idx1, off1, desc2, n2, idx2, off2, n_buckets, bp);
+    if (s != ORBX_OK) return s;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    std::vector<uint8_t> matched2(n2, 0);
+    RotHist hist(1.0f / kHistoLength);
+    int nm = 0;
+    for (int b = 0; b < n_buckets; ++b) {
+        const int jb = off2[b], je = off2[b + 1];
+        for (int e = off1[b]; e < off1[b + 1]; ++e) {
+            const int i1 = idx1[e];
+            if (!valid1[i1]) continue;
+            const uint16_t* row = bp.dist.data() + bp.rowStart[e];
+            int best1 = 256, bestIdx2 = -1, best2 = 256;
+            for (int j = jb; j < je; ++j) {
+                const int i2 = idx2[j];
+                if (matched2[i2] || !valid2[i2]) continue;
+                const int d = row[j - jb];
+                if (d < best1) { best2 = best1; best1 = d; bestIdx2 = i2; }
+                else if (d < best2) best2 = d;
+            }
+            if (best1 < 50 && (float)best1 < nn_ratio * (float)best2) {
+                matches12[i1] = bestIdx2;
+                matched2[bestIdx2] = 1;
+                if (check_orientation)
+                    ORBX_REQUIRE(hist.add(angle1[i1], angle2[bestIdx2], i1), "rotation bin out of range");
+                ++nm;
+            }
+        }
+    }
+    if (check_orientation) hist.for_each_rejected([&](int i1) { matches12[i1] = -1; --nm; });
+    *n_matches = nm;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_search_for_triangulation(const orbx_keypoint* kps1, const uint8_t* desc1, const uint8_t* free1,
+                                                     const float* uright1, int n1, const int* idx1, const int* off1,
+                                                     const orbx_keypoint* kps2, const uint8_t* desc2, const uint8_t* free2,
+                                                     const float* uright2, int n2, const int* idx2, const int* off2,
+                                                     int n_buckets, const orbx_epipolar* geom, int only_stereo, int coarse,
+                                                     int check_orientation, int* matches12, int* n_matches) {
+    ORBX_REQUIRE(n_matches && geom && (n1 == 0 || (kps1 && free1 && matches12)) && (n2 == 0 || (kps2 && free2)), "null argument");
+    ORBX_REQUIRE(geom->n_levels > 0 && geom->scale_factors2 && geom->level_sigma2_2, "level tables missing");
+    for (int i = 0; i < n2; ++i)
+        ORBX_REQUIRE(kps2[i].octave >= 0 && kps2[i].octave < geom->n_levels, "keypoint %d of the second keyframe: octave out of range", i);
+    BucketPairs bp;
+    orbx_status s = bucket_allpairs_impl(desc1, n1, idx1, off1, desc2, n2, idx2, off2, n_buckets, bp);
+    if (s != ORBX_OK) return s;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    RotHist hist(1.0f / kHistoLength);
+    const float* F = geom->F12;
+    int nm = 0;
+    for (int b = 0; b < n_buckets; ++b) {
+        const int jb = off2[b], je = off2[b + 1];
+        for (int e = off1[b]; e < off1[b + 1]; ++e) {
+            const int i1 = idx1[e];
+            if (!free1[i1]) continue;                                   // already has a map point (:1037)
+            const bool stereo1 = uright1 && uright1[i1] >= 0;
+            if (only_stereo && !stereo1) continue;
+            const orbx_keypoint& kp1 = kps1[i1];
+            const uint16_t* row = bp.dist.data() + bp.rowStart[e];
+            int bestDist = 50, bestIdx2 = -1;
+            for (int j = jb; j < je; ++j) {
+                const int i2 = idx2[j];
+                if (!free2[i2]) continue;                               // vbMatched2 is never set in the reference
+                const bool stereo2 = uright2 && uright2[i2] >= 0;
+                if (only_stereo && !stereo2) continue;
+                const int d = row[j - jb];
+                if (d > 50 || d > bestDist) continue;
+                const orbx_keypoint& kp2 = kps2[i2];
+                if (!stereo1 && !stereo2) {                              // too close to the epipole (:1089-1097)
+                    const float distex = geom->epipole_x - kp2.x, distey = geom->epipole_y - kp2.y;
+                    if (distex * distex + distey * distey < 100 * geom->scale_factors2[kp2.octave]) continue;
+                }
+                bool ok = coarse != 0;
+                if (!ok) {                                               // Pinhole::epipolarConstrain (Pinhole.cpp:126-140)
+                    const float a = kp1.x * F[0] + kp1.y * F[3] + F[6];
+                    const float bb = kp1.x * F[1] + kp1.y * F[4] + F[7];
+                    const float c = kp1.x * F[2] + kp1.y * F[5] + F[8];
+                    const float num = a * kp2.x + bb * kp2.y + c;
+                    const float den = a * a + bb * bb;
+                    if (den != 0) {
+                        const float dsqr = num * num / den;
+                        ok = dsqr < 3.84 * geom->level_sigma2_2[kp2.octave];
+                    }
+                }
+                if (ok) { bestIdx2 = i2; bestDist = d; }
+            }
+            if (bestIdx2 >= 0) {
+                matches12[i1] = bestIdx2;
+                ++nm;
+                if (check_orientation)
+                    ORBX_REQUIRE(hist.add(kp1.angle, kps2[bestIdx2].angle, i1), "rotation bin out of range");
+            }
+        }
+    }
+    if (check_orientation) hist.for_each_rejected([&](int i1) { matches12[i1] = -1; --nm; });
+    *n_matches = nm;
     return ORBX_OK;
 }

@@ -61,6 +61,158 @@ class ORBmatcher:
                                               ptr(taken), ptr(out), C.byref(nm)))
         return out, nm.value
 
+    # ---- the other order-dependent searches (flattened inputs, see include/orbx.h) ----------
+    @staticmethod
+    def _frame(kps, desc, uright):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        return kps, _desc(desc) if len(kps) else np.zeros((0, 32), np.uint8), \
+            None if uright is None else np.ascontiguousarray(uright, np.float32)
+
+    @staticmethod
+    def _queries(queries, query_desc):
+        queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+        return queries, _desc(query_desc) if len(queries) else np.zeros((0, 32), np.uint8)
+
+    def SearchWindowBest(self, kps, desc, uright, bounds, queries, query_desc, max_dist, taken=None,
+                         query_marks=None, query_angle=None, rot_factor=1.0 / HISTO_LENGTH):
+        """Loop of SearchByProjection(Cur, Last) / (Cur, KF, sFound) / (KF, Sim3, points) and
+        Fuse(KF, Sim3, points) (ORBmatcher.cc:1761-2094, :476-693, :1409-1524).  query_angle is
+        used only when the matcher checks orientation.  Returns (match per query, query per
+        keypoint, number of matches as the reference counts them); taken is updated in place."""
+        kps, desc, ur = self._frame(kps, desc, uright)
+        queries, query_desc = self._queries(queries, query_desc)
+        if taken is not None:
+            assert taken.dtype == np.uint8 and taken.flags.c_contiguous and len(taken) == len(kps)
+        marks = None if query_marks is None else np.ascontiguousarray(query_marks, np.uint8)
+        qa = None
+        if query_angle is not None and self.mbCheckOrientation:
+            qa = np.ascontiguousarray(query_angle, np.float32)
+        out = np.full(len(queries), -1, np.int32)
+        kpm = np.full(len(kps), -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_search_window_best(ptr(kps), ptr(desc), ptr(ur), len(kps), *map(float, bounds), ptr(queries),
+                                            ptr(query_desc), len(queries), float(max_dist), ptr(taken), ptr(marks),
+                                            ptr(qa), float(np.float32(rot_factor)), ptr(out), ptr(kpm), C.byref(nm)))
+        return out, kpm, nm.value
+
+    def Fuse(self, kps, desc, uright, bounds, queries, query_desc, inv_level_sigma2):
+        """Matching part of Fuse(KF, MapPoints, th, bRight) (ORBmatcher.cc:1214-1407)."""
+        kps, desc, ur = self._frame(kps, desc, uright)
+        queries, query_desc = self._queries(queries, query_desc)
+        sig = np.ascontiguousarray(inv_level_sigma2, np.float32)
+        out = np.full(len(queries), -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_fuse_search(ptr(kps), ptr(desc), ptr(ur), len(kps), *map(float, bounds), ptr(queries),
+                                     ptr(query_desc), len(queries), ptr(sig), len(sig), ptr(out), C.byref(nm)))
+        return out, nm.value
+
+    def SearchBySim3(self, kps1, desc1, bounds1, kps2, desc2, bounds2, into2, into1):
+        """SearchBySim3 (ORBmatcher.cc:1526-1743).  into2 = (queries, descriptors, source keypoint
+        of KF1) for KF1's map points projected into KF2; into1 the converse."""
+        kps1, desc1, _ = self._frame(kps1, desc1, None)
+        kps2, desc2, _ = self._frame(kps2, desc2, None)
+        q2, d2 = self._queries(into2[0], into2[1])
+        q1, d1 = self._queries(into1[0], into1[1])
+        s1 = np.ascontiguousarray(into2[2], np.int32)
+        s2 = np.ascontiguousarray(into1[2], np.int32)
+        b1 = np.ascontiguousarray(bounds1, np.float32)
+        b2 = np.ascontiguousarray(bounds2, np.float32)
+        out = np.full(len(kps1), -1, np.int32)
+        nf = C.c_int()
+        check(lib().orbx_search_by_sim3(ptr(kps1), ptr(desc1), len(kps1), ptr(b1), ptr(kps2), ptr(desc2), len(kps2),
+                                        ptr(b2), ptr(q2), ptr(d2), ptr(s1), len(q2), ptr(q1), ptr(d1), ptr(s2), len(q1),
+                                        ptr(out), C.byref(nf)))
+        return out, nf.value
+
+    def SearchForInitialization(self, kps1, desc1, kps2, desc2, bounds, prev_matched, windowSize=10):
+        """SearchForInitialization (ORBmatcher.cc:695-808); prev_matched [n1, 2] float32 is
+        updated in place.  Returns (vnMatches12, number of matches)."""
+        kps1, desc1, _ = self._frame(kps1, desc1, None)
+        kps2, desc2, _ = self._frame(kps2, desc2, None)
+        assert prev_matched.dtype == np.float32 and prev_matched.flags.c_contiguous and prev_matched.shape == (len(kps1), 2)
+        out = np.full(len(kps1), -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_search_for_initialization(ptr(kps1), ptr(desc1), len(kps1), ptr(kps2), ptr(desc2), len(kps2),
+                                                   *map(float, bounds), ptr(prev_matched), int(windowSize),
+                                                   self.mfNNratio, int(self.mbCheckOrientation), ptr(out), C.byref(nm)))
+        return out, nm.value
+
+    def SearchByBoW(self, descKF, angleKF, validKF, featvecKF, descF, angleF, featvecF, n_left=-1):
+        """SearchByBoW(KeyFrame, Frame) (ORBmatcher.cc:235-474).  featvec = (idx, off) CSR over the
+        vocabulary nodes both feature vectors share.  Returns (KF keypoint per frame keypoint, n)."""
+        descKF, descF = _desc(descKF), _desc(descF)
+        a = [np.ascontiguousarray(angleKF, np.float32), np.ascontiguousarray(validKF, np.uint8),
+             np.ascontiguousarray(featvecKF[0], np.int32), np.ascontiguousarray(featvecKF[1], np.int32)]
+        b = [np.ascontiguousarray(angleF, np.float32), np.ascontiguousarray(featvecF[0], np.int32),
+             np.ascontiguousarray(featvecF[1], np.int32)]
+        out = np.full(len(descF), -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_search_by_bow(ptr(descKF), ptr(a[0]), ptr(a[1]), len(descKF), ptr(a[2]), ptr(a[3]), ptr(descF),
+                                       ptr(b[0]), len(descF), int(n_left), ptr(b[1]), ptr(b[2]), len(a[3]) - 1,
+                                       self.mfNNratio, int(self.mbCheckOrientation), ptr(out), C.byref(nm)))
+        return out, nm.value
+
+    def SearchByBoWKeyFrames(self, desc1, angle1, valid1, featvec1, desc2, angle2, valid2, featvec2):
+        """SearchByBoW(KeyFrame, KeyFrame) (ORBmatcher.cc:824-966)."""
+        desc1, desc2 = _desc(desc1), _desc(desc2)
+        a = [np.ascontiguousarray(angle1, np.float32), np.ascontiguousarray(valid1, np.uint8),
+             np.ascontiguousarray(featvec1[0], np.int32), np.ascontiguousarray(featvec1[1], np.int32)]
+        b = [np.ascontiguousarray(angle2, np.float32), np.ascontiguousarray(valid2, np.uint8),
+             np.ascontiguousarray(featvec2[0], np.int32), np.ascontiguousarray(featvec2[1], np.int32)]
+        out = np.full(len(desc1), -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_search_by_bow_keyframes(ptr(desc1), ptr(a[0]), ptr(a[1]), len(desc1), ptr(a[2]), ptr(a[3]),
+                                                 ptr(desc2), ptr(b[0]), ptr(b[1]), len(desc2), ptr(b[2]), ptr(b[3]),
+                                                 len(a[3]) - 1, self.mfNNratio, int(self.mbCheckOrientation),
+                                                 ptr(out), C.byref(nm)))
+        return out, nm.value
+
+    def SearchForTriangulation(self, kps1, desc1, free1, uright1, featvec1, kps2, desc2, free2, uright2, featvec2,
+                               F12, epipole, scale_factors2, level_sigma2_2, bOnlyStereo=False, bCoarse=False):
+        """SearchForTriangulation (ORBmatcher.cc:968-1212), pinhole cameras."""
+        kps1, desc1, ur1 = self._frame(kps1, desc1, uright1)
+        kps2, desc2, ur2 = self._frame(kps2, desc2, uright2)
+        a = [np.ascontiguousarray(free1, np.uint8), np.ascontiguousarray(featvec1[0], np.int32),
+             np.ascontiguousarray(featvec1[1], np.int32)]
+        b = [np.ascontiguousarray(free2, np.uint8), np.ascontiguousarray(featvec2[0], np.int32),
+             np.ascontiguousarray(featvec2[1], np.int32)]
+        sf = np.ascontiguousarray(scale_factors2, np.float32)
+        sg = np.ascontiguousarray(level_sigma2_2, np.float32)
+        geom = Epipolar()
+        geom.F12[:] = [float(v) for v in np.asarray(F12, np.float32).reshape(9)]
+        geom.epipole_x, geom.epipole_y = float(epipole[0]), float(epipole[1])
+        geom.scale_factors2 = sf.ctypes.data_as(C.POINTER(C.c_float))
+        geom.level_sigma2_2 = sg.ctypes.data_as(C.POINTER(C.c_float))
+        geom.n_levels = len(sf)
+        out = np.full(len(kps1), -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_search_for_triangulation(ptr(kps1), ptr(desc1), ptr(a[0]), ptr(ur1), len(kps1), ptr(a[1]),
+                                                  ptr(a[2]), ptr(kps2), ptr(desc2), ptr(b[0]), ptr(ur2), len(kps2),
+                                                  ptr(b[1]), ptr(b[2]), len(a[2]) - 1, C.byref(geom), int(bOnlyStereo),
+                                                  int(bCoarse), int(self.mbCheckOrientation), ptr(out), C.byref(nm)))
+        return out, nm.value
+
+
+class Epipolar(C.Structure):
+    """orbx_epipolar (include/orbx.h)."""
+    _fields_ = [("F12", C.c_float * 9), ("epipole_x", C.c_float), ("epipole_y", C.c_float),
+                ("scale_factors2", C.POINTER(C.c_float)), ("level_sigma2_2", C.POINTER(C.c_float)),
+                ("n_levels", C.c_int)]
+
+
+def bucket_allpairs(desc1, idx1, off1, desc2, idx2, off2):
+    """Distances between all entries of the same node (row_start per idx1 entry, uint16 distances)."""
+    desc1, desc2 = _desc(desc1), _desc(desc2)
+    idx1, idx2 = np.ascontiguousarray(idx1, np.int32), np.ascontiguousarray(idx2, np.int32)
+    off1, off2 = np.ascontiguousarray(off1, np.int32), np.ascontiguousarray(off2, np.int32)
+    rs = np.zeros(len(idx1) + 1, np.int32)
+    cap = int(sum(int(off1[b + 1] - off1[b]) * int(off2[b + 1] - off2[b]) for b in range(len(off1) - 1)))
+    dist = np.zeros(max(cap, 1), np.uint16)
+    n = C.c_size_t()
+    check(lib().orbx_bucket_allpairs(ptr(desc1), len(desc1), ptr(idx1), ptr(off1), ptr(desc2), len(desc2), ptr(idx2),
+                                     ptr(off2), len(off1) - 1, ptr(rs), ptr(dist), cap, C.byref(n)))
+    return rs, dist[:n.value].copy()
+
 
 def window_candidates(kps, desc, uright, bounds, queries, query_desc):
     """Ordered candidates of Frame::GetFeaturesInArea per query with their distances (CSR)."""

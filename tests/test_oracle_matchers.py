@@ -1,0 +1,115 @@
+"""Hand-derivable known answers for the oracle's restatements of the order-dependent ORBmatcher
+loops (the reference has no tests for them): tie rules, the "taken" rule, thresholds, the
+rotation histogram with its 10 % rule, and the replace-on-equal rule of SearchForTriangulation."""
+import numpy as np
+
+BOUNDS = (0.0, 640.0, 0.0, 480.0)
+
+
+def _kps(O, xy, octave=0, angle=0.0):
+    k = np.zeros(len(xy), O.KP_DTYPE)
+    k["x"], k["y"] = np.array(xy, np.float32).T
+    k["octave"] = octave
+    k["angle"] = angle
+    return k
+
+
+def _desc_with_bits(n_bits_list):
+    d = np.zeros((len(n_bits_list), 32), np.uint8)
+    for i, nb in enumerate(n_bits_list):
+        for b in range(nb):
+            d[i, b >> 3] |= np.uint8(1 << (b & 7))
+    return d
+
+
+def test_window_best_taken_rule_and_ties(oracle):
+    O = oracle
+    kps = _kps(O, [(100, 100), (101, 100), (102, 100)])
+    desc = _desc_with_bits([4, 4, 9])            # distances to the zero descriptor: 4, 4, 9
+    g = O.Grid(kps, *BOUNDS)
+    q = dict(qx=[100.5] * 3, qy=[100.0] * 3, qxr=[0] * 3, qradius=[5.0] * 3, qmin=[-1] * 3, qmax=[-1] * 3)
+    qd = np.zeros((3, 32), np.uint8)
+    # occupied keypoints are skipped: query 0 takes keypoint 0 (first of the tie), 1 takes 1, 2 takes 2
+    kpm, taken, n = O.search_window_best(g, desc, None, q["qx"], q["qy"], q["qxr"], q["qradius"], q["qmin"], q["qmax"],
+                                         qd, 100.0, np.zeros(3, np.uint8), None, None)
+    assert n == 3 and list(kpm) == [0, 1, 2] and list(taken) == [1, 1, 1]
+    # map points without observations do not occupy: every query lands on keypoint 0, the last one owns it
+    kpm, taken, n = O.search_window_best(g, desc, None, q["qx"], q["qy"], q["qxr"], q["qradius"], q["qmin"], q["qmax"],
+                                         qd, 100.0, np.zeros(3, np.uint8), np.zeros(3, np.uint8), None)
+    assert n == 3 and list(kpm) == [2, -1, -1]
+    # threshold: best = 4 is accepted at max_dist 4, rejected at 3
+    kpm, _, n = O.search_window_best(g, desc, None, q["qx"][:1], q["qy"][:1], q["qxr"][:1], q["qradius"][:1],
+                                     q["qmin"][:1], q["qmax"][:1], qd[:1], 3.0, None, None, None)
+    assert n == 0 and list(kpm) == [-1, -1, -1]
+
+
+def test_rotation_histogram_prunes_minor_bins(oracle):
+    O = oracle
+    n = 24
+    kps = _kps(O, [(50 + 20 * i, 200) for i in range(n)], angle=0.0)
+    desc = np.zeros((n, 32), np.uint8)
+    g = O.Grid(kps, *BOUNDS)
+    qx = [50 + 20 * i for i in range(n)]
+    qa = np.full(n, 10.0, np.float32)            # rot = 10 deg -> bin round(10 / 30) = 0
+    qa[-2:] = 100.0                              # two matches in bin round(100 / 30) = 3 (< 10 % of 22 -> pruned)
+    kpm, _, nm = O.search_window_best(g, desc, None, qx, [200.0] * n, [0] * n, [3.0] * n, [-1] * n, [-1] * n,
+                                      np.zeros((n, 32), np.uint8), 100.0, np.zeros(n, np.uint8), None, qa, 1.0 / 30)
+    assert nm == 22 and list(kpm[:22]) == list(range(22)) and list(kpm[22:]) == [-1, -1]
+    qa[-3:] = 100.0                              # three of 24: 3 >= 0.1 * 21 -> kept as second maximum
+    kpm, _, nm = O.search_window_best(g, desc, None, qx, [200.0] * n, [0] * n, [3.0] * n, [-1] * n, [-1] * n,
+                                      np.zeros((n, 32), np.uint8), 100.0, np.zeros(n, np.uint8), None, qa, 1.0 / 30)
+    assert nm == 24 and list(kpm) == list(range(24))
+
+
+def test_bow_keyframes_strict_threshold_and_used_once(oracle):
+    O = oracle
+    d1 = np.zeros((2, 32), np.uint8)
+    d2 = _desc_with_bits([50, 49, 120])
+    idx1, off1 = [0, 1], [0, 2]
+    idx2, off2 = [0, 1, 2], [0, 3]
+    ones = np.ones(3, np.uint8)
+    # keypoint 0 of KF1: best 49 (< 50 strict), second 50 -> 49 < 0.99 * 50; keypoint 1: best is 50 -> rejected
+    m, n = O.search_by_bow_keyframes(d1, np.zeros(2), ones[:2], idx1, off1, d2, np.zeros(3), ones, idx2, off2, 0.99, False)
+    assert n == 1 and list(m) == [1, -1]
+    # ratio test: 49 < 0.9 * 50 = 45 fails
+    m, n = O.search_by_bow_keyframes(d1, np.zeros(2), ones[:2], idx1, off1, d2, np.zeros(3), ones, idx2, off2, 0.9, False)
+    assert n == 0
+
+
+def test_triangulation_later_equal_distance_replaces(oracle):
+    O = oracle
+    k1 = _kps(O, [(300, 200)])
+    k2 = _kps(O, [(100, 100), (120, 100), (140, 100)])
+    d1 = np.zeros((1, 32), np.uint8)
+    d2 = _desc_with_bits([30, 30, 51])
+    F = np.zeros(9, np.float32)
+    sf = np.ones(8, np.float32)
+    m, n = O.search_for_triangulation(k1, d1, [1], None, [0], [0, 1], k2, d2, [1, 1, 1], None, [0, 1, 2], [0, 3],
+                                      F, (1000.0, 1000.0), sf, sf, False, True, False)
+    assert n == 1 and list(m) == [1]             # 30, then 30 again (not > best) replaces; 51 > 50 skipped
+    # epipole 5 px from keypoint 1: 25 < 100 * scale -> that candidate is skipped, keypoint 0 stays
+    m, n = O.search_for_triangulation(k1, d1, [1], None, [0], [0, 1], k2, d2, [1, 1, 1], None, [0, 1, 2], [0, 3],
+                                      F, (125.0, 100.0), sf, sf, False, True, False)
+    assert n == 1 and list(m) == [0]
+    # epipolar gate: F12 = pure x-translation -> line y' = y; no keypoint of image 2 lies on y = 200
+    F = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32)
+    m, n = O.search_for_triangulation(k1, d1, [1], None, [0], [0, 1], k2, d2, [1, 1, 1], None, [0, 1, 2], [0, 3],
+                                      F, (1000.0, 1000.0), sf, sf, False, False, False)
+    assert n == 0
+    k2["y"][0] = 201.0                           # 1 px off the line: 1 < 3.84 -> accepted
+    m, n = O.search_for_triangulation(k1, d1, [1], None, [0], [0, 1], k2, d2, [1, 1, 1], None, [0, 1, 2], [0, 3],
+                                      F, (1000.0, 1000.0), sf, sf, False, False, False)
+    assert n == 1 and list(m) == [0]
+
+
+def test_initialization_reassigns_to_better_match(oracle):
+    O = oracle
+    k1 = _kps(O, [(100, 100), (104, 100)])
+    k2 = _kps(O, [(102, 100)])
+    d1 = _desc_with_bits([10, 3])                # distances to the single candidate: 10, then 3
+    d2 = np.zeros((1, 32), np.uint8)
+    g2 = O.Grid(k2, *BOUNDS)
+    prev = np.array([[100, 100], [104, 100]], np.float32)
+    m, prev2, n = O.search_for_initialization(k1, d1, g2, d2, prev, 20, 0.9, False)
+    assert n == 1 and list(m) == [-1, 0]         # keypoint 0 matched first (10), then lost it to keypoint 1 (3 < 10)
+    assert list(prev2[1]) == [102, 100] and list(prev2[0]) == [100, 100]
