@@ -877,6 +877,26 @@ __device__ __forceinline__ void sincos_f32(float xf, float* s_out, float* c_out)
     *c_out = (float)c;
 }
 
+// Weight bytes of the orientation disc: entry [|v| * 8 + g] = { (u + 15) for the 4 columns
+// u = 4g - 15 .. 4g - 12 that satisfy |u| <= umax[|v|] (else 0), 1 for the same columns (else 0) }.
+struct OrientWeights { uint32_t w[256]; };
+constexpr OrientWeights make_orient_weights() {
+    OrientWeights t{};
+    const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};   // ORBextractor.cc:520-535
+    for (int av = 0; av < 16; ++av)
+        for (int g = 0; g < 8; ++g) {
+            uint32_t wu = 0, w1 = 0;
+            for (int k = 0; k < 4; ++k) {
+                const int u = 4 * g - 15 + k, au = u < 0 ? -u : u;
+                if (au <= umax[av]) { wu |= (uint32_t)(u + 15) << (8 * k); w1 |= 1u << (8 * k); }
+            }
+            t.w[2 * (av * 8 + g)] = wu;
+            t.w[2 * (av * 8 + g) + 1] = w1;
+        }
+    return t;
+}
+__constant__ OrientWeights c_orientW = make_orient_weights();
+
 __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo* __restrict__ geo,
                                                               const uint8_t* __restrict__ pyr, long long frameStride,
                                                               const OrbxLevelKp* __restrict__ levelKps,
@@ -885,6 +905,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
                                                               uint8_t* __restrict__ outDesc, int capacity) {
     __shared__ __align__(16) uint8_t s_raw[kDescWaves][kRawW * kRawP];    // raw patch, later the blurred core
     __shared__ __align__(16) uint16_t s_hor[kDescWaves][kRawW * kBlurP];
+    __shared__ uint2 s_orientW[128];
+    if (threadIdx.x < 128) s_orientW[threadIdx.x] = make_uint2(c_orientW.w[2 * threadIdx.x], c_orientW.w[2 * threadIdx.x + 1]);
 
     // keypoints of one frame read the same few level images: keep a frame on one XCD
     const int logicalBlock = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
@@ -921,7 +943,6 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     const int xa = px0 & ~15;
     const bool interior = px0 >= 0 && py0 >= 0 && cx + kRawR < G.w && cy + kRawR < G.h && xa + kRawP <= G.pitch;
     const int ox = interior ? px0 - xa : 0;
-    const uint8_t* raw = rawBase + ox;
     if (active) {
         if (interior) {
             for (int i = lane; i < kRawW * (kRawP / 16); i += 64) {
@@ -940,15 +961,24 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     __syncthreads();
 
     // ---- orientation: m10 = sum u*I, m01 = sum v*I over the radius-15 disc ----
+    // item = (row v, group of 4 columns u0..u0+3, u0 = 4g - 15): the 4 pixels come as one byte
+    // window of two dwords; sum((u + 15) * I) and sum(I) over the columns inside the disc are two
+    // v_dot4_u32_u8 against the row's weight bytes (zero outside the disc).
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < 31 * 31; i += 64) {
-        const int v = i / 31 - 15, u = i % 31 - 15;
-        const int av = v < 0 ? -v : v, au = u < 0 ? -u : u;
-        // umax[|v|] = 15 15 15 15 14 14 14 13 13 12 11 10 9 8 6 3, four bits per entry
-        if (au <= (int)((0x3689ABCDDEEEFFFFull >> (4 * av)) & 15ull)) {
-            const int p = raw[(kRawR + v) * kRawP + kRawR + u];
-            m10 += u * p;
-            m01 += v * p;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = lane + 64 * it;
+        if (i < 31 * 8) {
+            const int row = i >> 3, g = i & 7;
+            const int v = row - 15, av = v < 0 ? -v : v;
+            const uint2 w = s_orientW[av * 8 + g];
+            const int b0 = ox + (kRawR - 15) + 4 * g;
+            const uint32_t* rowp = reinterpret_cast<const uint32_t*>(rawBase + (kRawR + v) * kRawP) + (b0 >> 2);
+            const uint32_t px4 = __builtin_amdgcn_alignbyte(rowp[1], rowp[0], b0 & 3);
+            const int sumI = (int)__builtin_amdgcn_udot4(px4, w.y, 0u, false);
+            const int sumUI = (int)__builtin_amdgcn_udot4(px4, w.x, 0u, false);
+            m10 += sumUI - 15 * sumI;
+            m01 += v * sumI;
         }
     }
 #pragma unroll
