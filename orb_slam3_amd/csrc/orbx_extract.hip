@@ -920,7 +920,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
         if (o >= 0 && o < geo->lv[l].kpCap) { level = l; idx = o; }
     }
     // Waves without a keypoint stay in step (they only skip the work) so that every
-    // wave of the workgroup reaches the barriers below.
+    // wave of the workgroup reaches the barrier below.
     bool active = level >= 0;
     if (active) active = idx < kpCount[frame * nl + level];
     const OrbxLevelGeo& G = geo->lv[active ? level : 0];
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
             if (c0 + k < kBlurW) hor[(c0 + k) * kHorTP + r] = (uint16_t)h;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
     // vertical: item = (column c, 8 output rows r0..r0+7): 14 row sums = 7 packed pairs, four
     // v_dot2_u32_u16 per output; odd rows use the weight pairs shifted by one tap.
     for (int i = lane; active && i < kBlurW * 5; i += 64) {
@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
             if (r0 + k < kBlurW) blur[(r0 + k) * kBlurP + c] = (uint8_t)(sum >> 16);
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
 
     if (!active) return;
     // ---- steered BRIEF: lane handles comparisons 4*lane .. 4*lane+3 ----
