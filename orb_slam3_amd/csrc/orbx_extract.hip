@@ -239,7 +239,11 @@ __device__ __forceinline__ bool in_any_rect(float X, float Y, const orbx_rect* r
 
 constexpr int kFastThreads = 128;
 
-__global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __restrict__ geo, const uint8_t* __restrict__ pyr,
+// kP = LDS tile pitch known at compile time (row steps and the 3-row look-ahead become
+// immediate offsets), or 0 to take it from the geometry.
+template <int kP>
+__global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __restrict__ geo, const int4* __restrict__ cells,
+                                                       const uint8_t* __restrict__ pyr,
                                                        long long frameStride, OrbxCand* __restrict__ cands,
                                                        int* __restrict__ candCount, int iniTh, int minTh,
                                                        const orbx_rect* __restrict__ rects, int nrects,
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     // strengths are known the image tile is reused for the per-pixel keep flags.
     extern __shared__ __align__(16) unsigned char fast_smem[];
     __shared__ int s_nQueue, s_nIni, s_nMin;
-    const int P = geo->tileP, R = geo->tileR;
+    const int P = kP ? kP : geo->tileP, R = geo->tileR;
     uint8_t* tile = fast_smem;
     uint8_t* strength = tile + P * R;
     unsigned short* s_queue = reinterpret_cast<unsigned short*>(strength + P * R);
@@ -260,30 +264,36 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     const int logical = xcd_remap(blockIdx.y * nCellsAll + blockIdx.x, nCellsAll * gridDim.y);
     const int frame = logical / nCellsAll;
     const int cellAll = logical - frame * nCellsAll;
-    int level = 0;
+    // per-cell constants precomputed on the host: {x0 | y0 << 16, tw | th << 8 | level << 16,
+    // index among the level's processed cells (row-major), cells from this one to the level's last}
+    const int4 CI = cells[cellAll];
+    const int x0 = CI.x & 0xFFFF, y0 = CI.x >> 16;
+    const int tw = CI.y & 255, th = (CI.y >> 8) & 255, level = CI.y >> 16;
+    const int cell = CI.z;
     const int nl = geo->nlevels;
-    for (int l = 1; l < nl; ++l)
-        if (cellAll >= geo->lv[l].cellBase) level = l;
     const OrbxLevelGeo& G = geo->lv[level];
-    const int cell = cellAll - G.cellBase;              // index among processed cells, row-major
-    const int ci = cell / G.nColsP, cj = cell - ci * G.nColsP;
-    const int maxBX = G.w - kOrbxMinBorder, maxBY = G.h - kOrbxMinBorder;
-    const int x0 = kOrbxMinBorder + cj * G.wCell, y0 = kOrbxMinBorder + ci * G.hCell;
-    const int x1 = min(x0 + G.wCell + 6, maxBX), y1 = min(y0 + G.hCell + 6, maxBY);
-    const int tw = x1 - x0, th = y1 - y0;
     const int tid = threadIdx.x;
     const int xa = x0 & ~3, ox = x0 - xa;
-    const int rowDwords = (x1 - xa + 3) >> 2;           // <= P / 4
+    const int rowDwords = (x0 + tw - xa + 3) >> 2;      // <= P / 4
 
     if (tid == 0) { s_nQueue = 0; s_nIni = 0; s_nMin = 0; }
     const uint8_t* img = pyr + (long long)frame * frameStride + G.off;
     {
-        const float invRow = 1.0f / (float)rowDwords;
-        for (int i = tid; i < rowDwords * th; i += kFastThreads) {
-            const int y = (int)(((float)i + 0.5f) * invRow), xd = i - y * rowDwords;
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(img + (long long)(y0 + y) * G.pitch + xa + 4 * xd);
-            *reinterpret_cast<uint32_t*>(tile + y * P + 4 * xd) = v;
-            *reinterpret_cast<uint32_t*>(strength + y * P + 4 * xd) = 0u;
+        // lane -> (row, dword of the row); kFastThreads / (P / 4) rows per pass
+        const int RD = P >> 2;
+        const int rowsPerPass = kFastThreads / RD;
+        const int row = tid / RD, xd = tid - row * RD;
+        if (row < rowsPerPass && xd < rowDwords) {
+            const uint8_t* src = img + (long long)(y0 + row) * G.pitch + xa + 4 * xd;
+            uint8_t* dstT = tile + row * P + 4 * xd;
+            uint8_t* dstS = strength + row * P + 4 * xd;
+            const long long srcStep = (long long)rowsPerPass * G.pitch;
+            const int dstStep = rowsPerPass * P;
+            for (int y = row; y < th; y += rowsPerPass) {
+                *reinterpret_cast<uint32_t*>(dstT) = *reinterpret_cast<const uint32_t*>(src);
+                *reinterpret_cast<uint32_t*>(dstS) = 0u;
+                src += srcStep; dstT += dstStep; dstS += dstStep;
+            }
         }
     }
     __syncthreads();
@@ -310,21 +320,20 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
         for (int chunk = 0; chunk < bandRows; chunk += 28) {
             const int yc = yBeg + chunk;                       // first row of this chunk
             const int rows = min(28, bandRows - chunk);        // uniform
-            const uint8_t* c = T + (laneOn ? yc : 3) * P + (laneOn ? x : 3);
-            int w0 = c[-3 * P], w1 = c[-2 * P], w2 = c[-P], w3 = c[0], w4 = c[P], w5 = c[2 * P], w6 = c[3 * P];
-            unsigned mask = 0, bit = 1;   // bit i of mask = row yc + i survives
+            const uint8_t* c = T + (laneOn ? yc : 3) * P + (laneOn ? x : 3) - 3;   // 3 left of the centre: offsets stay >= 0
+            int w0 = c[3 - 3 * P], w1 = c[3 - 2 * P], w2 = c[3 - P], w3 = c[3], w4 = c[3 + P], w5 = c[3 + 2 * P], w6 = c[3 + 3 * P];
+            unsigned mask = 0;   // row yc + i of the chunk ends up in bit rows - 1 - i
             // one row: centre = a3, above = a0, below = a6; afterwards a0 receives row y + 4
 #define ORBX_FAST_ROW(a0, a1, a2, a3, a4, a5, a6, r)                                              \
             if ((r) < rows) {                                                                         \
                 const int v = a3, lo = v - lowTh, hi = v + lowTh;                                     \
-                const int pl = c[-3], pr = c[3];                                                      \
+                const int pl = c[0], pr = c[6];                                                       \
                 const int dmax = max(min(a0, a6), min(pl, pr));   /* dark: both pairs have one < lo */ \
                 const int bmin = min(max(a0, a6), max(pl, pr));   /* bright: both pairs have one > hi */\
                 const bool pass = (dmax < lo) || (bmin > hi);                                         \
-                mask |= pass ? bit : 0u;                                                              \
-                bit <<= 1;                                                                            \
+                mask = (mask << 1) | (pass ? 1u : 0u);                                                \
                 c += P;                                                                               \
-                a0 = c[3 * P];                                                                        \
+                a0 = c[3 + 3 * P];                                                                    \
             }
             for (int r = 0; r < rows; r += 7) {
                 ORBX_FAST_ROW(w0, w1, w2, w3, w4, w5, w6, r + 0)
@@ -336,17 +345,16 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
                 ORBX_FAST_ROW(w6, w0, w1, w2, w3, w4, w5, r + 6)
             }
 #undef ORBX_FAST_ROW
-            // drop rows past the lane's band / the cell
-            const int valid = yEnd - yc;
-            unsigned m = (valid <= 0) ? 0u : (valid >= 32 ? mask : (mask & ((1u << valid) - 1u)));
-            int cnt = 0;
-            cnt = __popc(m);
+            // keep the rows inside the lane's band / the cell: the first `valid` rows of the chunk
+            const int valid = min(yEnd - yc, rows);
+            unsigned m = (valid <= 0) ? 0u : (mask >> (rows - valid));
+            const int cnt = __popc(m);
             if (cnt) {
                 int base = atomicAdd(&s_nQueue, cnt);
                 while (m) {
-                    const int i = __ffs(m) - 1;
+                    const int i = __ffs(m) - 1;       // bit i = row yc + valid - 1 - i
                     m &= m - 1;
-                    s_queue[base++] = (unsigned short)(x | ((yc + i) << 7));
+                    s_queue[base++] = (unsigned short)(x | ((yc + valid - 1 - i) << 7));
                 }
             }
         }
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
 
     // Round trip: every corner found in the c-th processed cell is scaled to level 0 and
     // back once for each cell processed from its own to the last one of the level.
-    const int apps = G.nColsP * G.nRowsP - cell;
+    const int apps = CI.w;
     const float s = G.scale, inv = G.invScale;
     const float border = (float)kOrbxMinBorder;
     OrbxCand* out = cands + (long long)frame * geo->candTotal + G.candOff;
@@ -418,8 +426,8 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
         const int lx = rec & 127, ly = rec >> 7;
         if (!(T[ly * P + lx] & wantFlag)) continue;
         const int sc = score_at(S[ly * P + lx], useTh);
-        float x = __fadd_rn((float)lx, (float)(cj * G.wCell));
-        float y = __fadd_rn((float)ly, (float)(ci * G.hCell));
+        float x = __fadd_rn((float)lx, (float)(x0 - kOrbxMinBorder));
+        float y = __fadd_rn((float)ly, (float)(y0 - kOrbxMinBorder));
         bool erased = false;
         for (int a = 0; a < apps; ++a) {
             const float X = __fmul_rn(__fadd_rn(x, border), s);
@@ -1105,6 +1113,7 @@ struct orbx_extractor {
     OrbxErr* d_err = nullptr;
     OrbxErr* h_err = nullptr;      // pinned
     orbx_rect* d_rects = nullptr;
+    int4* d_cells = nullptr;       // FAST cell table
     int *d_xofs = nullptr, *d_yofs = nullptr;
     uint32_t *d_xcoef = nullptr, *d_ycoef = nullptr;
     size_t tapAlloc = 0;
@@ -1178,6 +1187,7 @@ static void free_geo_buffers(orbx_extractor* ex) {
     hipFree(ex->d_yofs); ex->d_yofs = nullptr;
     hipFree(ex->d_xcoef); ex->d_xcoef = nullptr;
     hipFree(ex->d_ycoef); ex->d_ycoef = nullptr;
+    hipFree(ex->d_cells); ex->d_cells = nullptr;
 }
 
 // Computes the level / cell / quadtree geometry for a w x h image and (re)allocates the
@@ -1239,6 +1249,7 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
         int mw = 0, mh = 0;
         for (int l = 0; l < P.nlevels; ++l) { mw = std::max(mw, g.lv[l].wCell + 6); mh = std::max(mh, g.lv[l].hCell + 6); }
         g.tileP = (mw + 3 + 3) & ~3;     // widest cell image + alignment shift, multiple of 4
+        if (g.tileP <= 48) g.tileP = 48; // the common 35..39-px cells share the kernel instance with a constant pitch
         g.tileR = mh;
         g.fastLds = 2 * g.tileP * g.tileR + 2 * ((mw - 6) * (mh - 6) + 4);
     }
@@ -1283,6 +1294,23 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
     ORBX_HIP_TRY(hipMemcpy(ex->d_yofs, yo.data(), tapY * sizeof(int), hipMemcpyHostToDevice));
     ORBX_HIP_TRY(hipMemcpy(ex->d_xcoef, xc.data(), tapX * sizeof(uint32_t), hipMemcpyHostToDevice));
     ORBX_HIP_TRY(hipMemcpy(ex->d_ycoef, yc.data(), tapY * sizeof(uint32_t), hipMemcpyHostToDevice));
+    {
+        // per-cell constants of the FAST kernel (one int4 per processed cell, all levels)
+        std::vector<int4> cells(std::max(g.totalCells, 1));
+        for (int l = 0; l < P.nlevels; ++l) {
+            const OrbxLevelGeo& L = g.lv[l];
+            const int maxBX = L.w - kOrbxMinBorder, maxBY = L.h - kOrbxMinBorder;
+            for (int c = 0; c < L.nColsP * L.nRowsP; ++c) {
+                const int ci = c / L.nColsP, cj = c - ci * L.nColsP;
+                const int x0 = kOrbxMinBorder + cj * L.wCell, y0 = kOrbxMinBorder + ci * L.hCell;
+                const int x1 = std::min(x0 + L.wCell + 6, maxBX), y1 = std::min(y0 + L.hCell + 6, maxBY);
+                cells[L.cellBase + c] = make_int4(x0 | (y0 << 16), (x1 - x0) | ((y1 - y0) << 8) | (l << 16), c,
+                                                  L.nColsP * L.nRowsP - c);
+            }
+        }
+        ORBX_HIP_TRY(hipMalloc((void**)&ex->d_cells, cells.size() * sizeof(int4)));
+        ORBX_HIP_TRY(hipMemcpy(ex->d_cells, cells.data(), cells.size() * sizeof(int4), hipMemcpyHostToDevice));
+    }
     ORBX_HIP_TRY(hipMemcpy(ex->d_geo, &g, sizeof(g), hipMemcpyHostToDevice));
     ex->geoValid = true;
     return ORBX_OK;
@@ -1400,8 +1428,14 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
                            ex->d_yofs, ex->d_ycoef);
     }
     mark(ex, st);
-    hipLaunchKernelGGL(k_fast, dim3(g.totalCells, nf), dim3(kFastThreads), (size_t)g.fastLds, st, ex->d_geo, ex->d_pyr, g.pyrBytes, ex->d_cands,
-                       ex->d_candCount, ex->prm.ini_th_fast, ex->prm.min_th_fast, ex->d_rects, ndyn, ex->d_err);
+    if (g.tileP == 48)
+        hipLaunchKernelGGL(k_fast<48>, dim3(g.totalCells, nf), dim3(kFastThreads), (size_t)g.fastLds, st, ex->d_geo, ex->d_cells,
+                           ex->d_pyr, g.pyrBytes, ex->d_cands, ex->d_candCount, ex->prm.ini_th_fast, ex->prm.min_th_fast,
+                           ex->d_rects, ndyn, ex->d_err);
+    else
+        hipLaunchKernelGGL(k_fast<0>, dim3(g.totalCells, nf), dim3(kFastThreads), (size_t)g.fastLds, st, ex->d_geo, ex->d_cells,
+                           ex->d_pyr, g.pyrBytes, ex->d_cands, ex->d_candCount, ex->prm.ini_th_fast, ex->prm.min_th_fast,
+                           ex->d_rects, ndyn, ex->d_err);
     mark(ex, st);
     const size_t qtLds = (size_t)g.maxNodeCap * 56 + kQtThreads * sizeof(int);
     hipLaunchKernelGGL(k_quadtree, dim3(nl, nf), dim3(kQtThreads), qtLds, st, ex->d_geo, ex->d_cands, ex->d_candCount,
