@@ -1356,6 +1356,7 @@ extern "C" orbx_status orbx_extractor_create(const orbx_params* p, orbx_extracto
         return fail(ORBX_ERR_HIP);
     }
     memset(ex->h_err, 0, sizeof(OrbxErr));
+    if (hipMemset(ex->d_err, 0, sizeof(OrbxErr)) != hipSuccess) { orbx_set_error("hipMemset failed"); return fail(ORBX_ERR_HIP); }
     st = setup_geometry(ex, p->max_width, p->max_height);
     if (st != ORBX_OK) return fail(st);
     ex->outCap = orbx_extractor_max_keypoints(ex);
@@ -1414,9 +1415,9 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
     const int nl = g.nlevels;
     ORBX_REQUIRE(ndyn >= 0 && ndyn <= kOrbxMaxRects, "at most %d dynamic rectangles", kOrbxMaxRects);
     if (ndyn > 0) ORBX_HIP_TRY(hipMemcpyAsync(ex->d_rects, dyn, ndyn * sizeof(orbx_rect), hipMemcpyHostToDevice, st));
+    // the only per-batch state that must start at zero; the quadtree writes every keypoint count and
+    // the error record is cleared when it is read (orbx_extract_status)
     ORBX_HIP_TRY(hipMemsetAsync(ex->d_candCount, 0, (size_t)nf * nl * sizeof(int), st));
-    ORBX_HIP_TRY(hipMemsetAsync(ex->d_kpCount, 0, (size_t)nf * nl * sizeof(int), st));
-    ORBX_HIP_TRY(hipMemsetAsync(ex->d_err, 0, sizeof(OrbxErr), st));
     if (ex->timing && ex->evUsed + kTimedStages + 1 > 4096 * (size_t)(kTimedStages + 1)) resolve_timing(ex);
     mark(ex, st);   // end of copy-in (its start is marked by the caller)
     for (int l = 1; l < nl; ++l) {
@@ -1447,7 +1448,6 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
     hipLaunchKernelGGL(k_describe, dim3((g.kpTotal + kDescWaves - 1) / kDescWaves, nf), dim3(64 * kDescWaves), 0, st,
                        ex->d_geo, ex->d_pyr, g.pyrBytes, ex->d_levelKps, ex->d_kpCount, d_kps, d_desc, capacity);
     mark(ex, st);
-    ORBX_HIP_TRY(hipMemcpyAsync(ex->h_err, ex->d_err, sizeof(OrbxErr), hipMemcpyDeviceToHost, st));
     ORBX_HIP_TRY(hipGetLastError());
     ex->lastFrames = nf;
     return ORBX_OK;
@@ -1474,7 +1474,12 @@ extern "C" orbx_status orbx_extract_batch_device(orbx_extractor* ex, const uint8
 
 extern "C" orbx_status orbx_extract_status(orbx_extractor* ex) {
     ORBX_REQUIRE(ex, "null handle");
+    // the caller has synchronised the stream the batch was launched on
+    ORBX_HIP_TRY(hipSetDevice(ex->device));
+    ORBX_HIP_TRY(hipMemcpy(ex->h_err, ex->d_err, sizeof(OrbxErr), hipMemcpyDeviceToHost));
     const OrbxErr e = *ex->h_err;
+    if (e.cand_overflow || e.kp_overflow || e.out_overflow || e.need_cand)
+        ORBX_HIP_TRY(hipMemset(ex->d_err, 0, sizeof(OrbxErr)));
     if (e.cand_overflow) {
         // regrow so that the next call fits
         while (ex->candShift > 0) {

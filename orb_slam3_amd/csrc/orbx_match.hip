@@ -273,111 +273,222 @@ struct OrbxPyrView {
     long long frameStride;      // bytes between frames (same for both: same geometry)
 };
 
-__global__ __launch_bounds__(256) void k_stereo_rows(const OrbxFrameGeo* __restrict__ geo, OrbxPyrView pv,
+constexpr int kStWaves = 8;          // waves per workgroup
+constexpr int kStPerWave = 4;        // left keypoints handled by one wave, one after the other
+constexpr int kStChunk = 2048;       // right keypoints staged in LDS at a time
+constexpr int kStBuckets = 256;      // row buckets of the staged keypoints (multiple of 64)
+
+__global__ __launch_bounds__(64 * kStWaves) void k_stereo_rows(const OrbxFrameGeo* __restrict__ geo, OrbxPyrView pv,
                                                      const orbx_keypoint* __restrict__ kpsL, const uint32_t* __restrict__ descL,
                                                      const int* __restrict__ countsL,
                                                      const orbx_keypoint* __restrict__ kpsR, const uint32_t* __restrict__ descR,
                                                      const int* __restrict__ countsR, int capacity, float mbf, float mb,
                                                      float* __restrict__ uRight, float* __restrict__ depth,
                                                      int* __restrict__ sadOut) {
+    // The row band, octave and x of every right keypoint are staged once per workgroup, bucketed by
+    // image row (counting sort in LDS); a left keypoint scans only the buckets its row band can touch.
+    __shared__ uint32_t s_rows[kStChunk];            // minr | (maxr + 1) << 16 (Frame.cc:980-990)
+    __shared__ float s_x[kStChunk];
+    __shared__ uint16_t s_idx[kStChunk];             // index inside the chunk
+    __shared__ uint8_t s_oct[kStChunk];
+    __shared__ int s_start[kStBuckets + 1];
+    __shared__ int s_fill[kStBuckets];
+    __shared__ uint32_t s_patch[kStWaves][11 * 4 + 11 * 8];   // left rows: 4 dwords each, right rows: 8 dwords each
+    __shared__ int s_part[kStWaves][128];
+    __shared__ unsigned int s_keys[kStWaves][kStPerWave];
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int iL = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nL = countsL[2 * frame], nR = countsR[2 * frame];
-    if (iL >= nL) return;
-    const long long rowL = (long long)frame * capacity + iL;
-    const orbx_keypoint kp = kpsL[rowL];
-    const int levelL = kp.octave;
-    const float vL = kp.y, uL = kp.x;
     const int nRows = geo->lv[0].h;
     const float minZ = mb, minD = 0.f;
     const float maxD = __fdiv_rn(mbf, minZ);
-    const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
+    const int iL0 = (blockIdx.x * kStWaves + wv) * kStPerWave;
+    if (blockIdx.x * kStWaves * kStPerWave >= nL) return;     // whole workgroup idle (uniform)
+    // bucket = row >> shift, at most kStBuckets buckets; a right keypoint at row y can only match left
+    // rows within reach = ceil(2 * largest scale) + 1 of y
+    int shift = 3;
+    while (((nRows - 1) >> shift) >= kStBuckets) ++shift;
+    const int reach = (int)ceilf(__fmul_rn(2.0f, geo->lv[geo->nlevels - 1].scale)) + 1;
 
-    if (lane == 0) { uRight[rowL] = -1.f; depth[rowL] = -1.f; sadOut[rowL] = -1; }
-    const long long rowInt = (long long)vL;   // vRowIndices[vL]: float -> size_t
-    if (rowInt < 0 || rowInt >= nRows) return;
-    if (maxU < 0) return;
-
-    const uint32_t* dL = descL + rowL * 8;
-    uint32_t ql[8];
+    // per left keypoint of this wave (all wave-uniform)
+    int rowOf[kStPerWave], levelOf[kStPerWave];
+    float minUOf[kStPerWave], maxUOf[kStPerWave];
+    unsigned int bestKey[kStPerWave];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) ql[k] = dL[k];
-    // (a) lexicographic min over (distance, right index) of the gated candidates
-    unsigned int bestKey = 0xFFFFFFFFu;
-    for (int iR = lane; iR < nR; iR += 64) {
-        const long long rowR = (long long)frame * capacity + iR;
-        const orbx_keypoint kr = kpsR[rowR];
-        const float r = __fmul_rn(2.0f, geo->lv[kr.octave].scale);
-        const int maxr = (int)ceilf(__fadd_rn(kr.y, r));
-        const int minr = (int)floorf(__fsub_rn(kr.y, r));
-        if (rowInt < minr || rowInt > maxr) continue;
-        if (kr.octave < levelL - 1 || kr.octave > levelL + 1) continue;
-        if (!(kr.x >= minU && kr.x <= maxU)) continue;
-        const uint32_t* dR = descR + rowR * 8;
-        int d = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) d += __popc(ql[k] ^ dR[k]);
-        if (d < 100) bestKey = min(bestKey, ((unsigned int)d << 20) | (unsigned int)iR);
+    for (int k = 0; k < kStPerWave; ++k) {
+        const int iL = iL0 + k;
+        rowOf[k] = -1; levelOf[k] = 0; minUOf[k] = 0.f; maxUOf[k] = 0.f; bestKey[k] = 0xFFFFFFFFu;
+        if (iL < nL) {
+            const long long rowL = (long long)frame * capacity + iL;
+            const orbx_keypoint kp = kpsL[rowL];
+            if (lane == 0) { uRight[rowL] = -1.f; depth[rowL] = -1.f; sadOut[rowL] = -1; }
+            const long long rowInt = (long long)kp.y;          // vRowIndices[vL]: float -> size_t
+            const float maxU = __fsub_rn(kp.x, minD);
+            if (rowInt >= 0 && rowInt < nRows && !(maxU < 0)) {
+                rowOf[k] = (int)rowInt; levelOf[k] = kp.octave;
+                minUOf[k] = __fsub_rn(kp.x, maxD); maxUOf[k] = maxU;
+            }
+        }
     }
+
+    // (a) lexicographic min over (distance, right index) of the gated candidates
+    for (int c0 = 0; c0 < nR; c0 += kStChunk) {
+        const int n = min(kStChunk, nR - c0);
+        const orbx_keypoint* KR = kpsR + (long long)frame * capacity + c0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < kStBuckets; i += 64 * kStWaves) { s_start[i + 1] = 0; s_fill[i] = 0; }
+        if (threadIdx.x == 0) s_start[0] = 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += 64 * kStWaves) {
+            const int b = min(max((int)KR[j].y, 0), nRows - 1) >> shift;
+            atomicAdd(&s_start[b + 1], 1);
+        }
+        __syncthreads();
+        if (wv == 0) {   // inclusive scan of the bucket counts: kStBuckets / 64 per lane
+            constexpr int per = kStBuckets / 64;
+            int v[per], sum = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) bestKey = min(bestKey, (unsigned int)__shfl_xor((int)bestKey, off));
-    if (bestKey == 0xFFFFFFFFu) return;
-    const int bestDist = (int)(bestKey >> 20), bestIdxR = (int)(bestKey & 0xFFFFFu);
-    if (!(bestDist < 75)) return;   // thOrbDist = (TH_HIGH + TH_LOW) / 2
+            for (int q = 0; q < per; ++q) { v[q] = s_start[1 + lane * per + q]; sum += v[q]; }
+            int incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+            int run = incl - sum;
+#pragma unroll
+            for (int q = 0; q < per; ++q) { run += v[q]; s_start[1 + lane * per + q] = run; }
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += 64 * kStWaves) {
+            const orbx_keypoint kr = KR[j];
+            const int b = min(max((int)kr.y, 0), nRows - 1) >> shift;
+            const int slot = s_start[b] + atomicAdd(&s_fill[b], 1);
+            const float r = __fmul_rn(2.0f, geo->lv[kr.octave].scale);
+            const int maxr = min(max((int)ceilf(__fadd_rn(kr.y, r)), -1), 65534);
+            const int minr = min(max((int)floorf(__fsub_rn(kr.y, r)), 0), 65535);   // rows are >= 0: clamping keeps the test
+            s_rows[slot] = (uint32_t)minr | ((uint32_t)(maxr + 1) << 16);
+            s_x[slot] = kr.x;
+            s_oct[slot] = (uint8_t)kr.octave;
+            s_idx[slot] = (uint16_t)j;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kStPerWave; ++k) {
+            if (rowOf[k] < 0) continue;
+            const uint32_t* dL = descL + ((long long)frame * capacity + iL0 + k) * 8;
+            const int row = rowOf[k], lvl = levelOf[k];
+            const int bLo = max(row - reach, 0) >> shift, bHi = min(row + reach, nRows - 1) >> shift;
+            const int jEnd = s_start[bHi + 1];
+            unsigned int key = bestKey[k];
+            for (int t = s_start[bLo] + lane; t < jEnd; t += 64) {
+                const uint32_t rr = s_rows[t];
+                if (row < (int)(rr & 0xFFFFu) || row + 1 > (int)(rr >> 16)) continue;
+                const int oc = s_oct[t];
+                if (oc < lvl - 1 || oc > lvl + 1) continue;
+                const float x = s_x[t];
+                if (!(x >= minUOf[k] && x <= maxUOf[k])) continue;
+                const int j = c0 + s_idx[t];
+                const uint32_t* dR = descR + ((long long)frame * capacity + j) * 8;
+                int d = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) d += __popc(dL[q] ^ dR[q]);
+                if (d < 100) key = min(key, ((unsigned int)d << 20) | (unsigned int)j);
+            }
+            bestKey[k] = key;
+        }
+    }
 
     // (b) sub-pixel refinement by correlation on the pyramid level of the left keypoint
-    const OrbxLevelGeo& G = geo->lv[levelL];
-    const float uR0 = kpsR[(long long)frame * capacity + bestIdxR].x;
-    const float sInv = G.invScale;
-    const float suL = roundf(__fmul_rn(kp.x, sInv)), svL = roundf(__fmul_rn(kp.y, sInv)), suR0 = roundf(__fmul_rn(uR0, sInv));
-    const int w = 5, L = 5;
-    const float iniu = __fsub_rn(__fadd_rn(suR0, (float)L), (float)w);
-    const float endu = __fadd_rn(__fadd_rn(__fadd_rn(suR0, (float)L), (float)w), 1.f);
-    if (iniu < 0 || endu >= (float)G.w) return;
-    const uint8_t* imL = pv.left + (long long)frame * pv.frameStride + G.off;
-    const uint8_t* imR = pv.right + (long long)frame * pv.frameStride + G.off;
-    const int y0 = (int)(svL - w), xl0 = (int)(suL - w), xr0 = (int)(suR0 - w);
-    int sad[11];
+    uint32_t* patch = s_patch[wv];
+    int* part = s_part[wv];
 #pragma unroll
-    for (int s = 0; s < 11; ++s) sad[s] = 0;
-    for (int p = lane; p < 121; p += 64) {
-        const int dy = p / 11, dx = p - dy * 11;
-        const int a = imL[(long long)(y0 + dy) * G.pitch + xl0 + dx];
-        const uint8_t* rrow = imR + (long long)(y0 + dy) * G.pitch + xr0 + dx;
+    for (int k = 0; k < kStPerWave; ++k) {
+        unsigned int key = bestKey[k];
 #pragma unroll
-        for (int s = 0; s < 11; ++s) {
-            const int b = rrow[s - L];
-            sad[s] += abs(a - b);
-        }
+        for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned int)__shfl_xor((int)key, off));
+        if (lane == 0) s_keys[wv][k] = key;
     }
-#pragma unroll
-    for (int s = 0; s < 11; ++s) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sad[s] += __shfl_xor(sad[s], off);
-    }
-    if (lane != 0) return;
-    int bestSad = INT_MAX, bestInc = 0;
-#pragma unroll
-    for (int s = 0; s < 11; ++s)
-        if (sad[s] < bestSad) { bestSad = sad[s]; bestInc = s - L; }
-    if (bestInc == -L || bestInc == L) return;
-    float d1 = 0.f, d2 = 0.f, d3 = 0.f;
-#pragma unroll
-    for (int s = 1; s < 10; ++s)
-        if (s - L == bestInc) { d1 = (float)sad[s - 1]; d2 = (float)sad[s]; d3 = (float)sad[s + 1]; }
-    const float delta = __fdiv_rn(__fsub_rn(d1, d3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
-    if (delta < -1 || delta > 1) return;
-    float bestuR = __fmul_rn(G.scale, __fadd_rn(__fadd_rn(suR0, (float)bestInc), delta));
-    float disparity = __fsub_rn(uL, bestuR);
-    if (disparity >= minD && disparity < maxD) {
-        if (disparity <= 0) {
-            disparity = 0.01f;                              // float(0.01)
-            bestuR = (float)((double)uL - 0.01);            // uL - 0.01 in double, then to float
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#pragma unroll 1
+    for (int k = 0; k < kStPerWave; ++k) {
+        const unsigned int key = s_keys[wv][k];
+        if (key == 0xFFFFFFFFu) continue;
+        const int bestDist = (int)(key >> 20), bestIdxR = (int)(key & 0xFFFFFu);
+        if (!(bestDist < 75)) continue;   // thOrbDist = (TH_HIGH + TH_LOW) / 2
+        const long long rowL = (long long)frame * capacity + iL0 + k;
+        const orbx_keypoint kp = kpsL[rowL];
+        const float uL = kp.x;
+        const OrbxLevelGeo& G = geo->lv[kp.octave];
+        const float uR0 = kpsR[(long long)frame * capacity + bestIdxR].x;
+        const float sInv = G.invScale;
+        const float suL = roundf(__fmul_rn(kp.x, sInv)), svL = roundf(__fmul_rn(kp.y, sInv)), suR0 = roundf(__fmul_rn(uR0, sInv));
+        const int w = 5, L = 5;
+        const float iniu = __fsub_rn(__fadd_rn(suR0, (float)L), (float)w);
+        const float endu = __fadd_rn(__fadd_rn(__fadd_rn(suR0, (float)L), (float)w), 1.f);
+        if (iniu < 0 || endu >= (float)G.w) continue;
+        const int y0 = (int)(svL - w), xl0 = (int)(suL - w), xr0 = (int)(suR0 - w) - L;   // xr0: first column of the right strip
+        // the windows of keypoints produced by the extractor always lie inside the level; anything else is not matched
+        if (y0 < 0 || y0 + 11 > G.h || xl0 < 0 || xl0 + 11 > G.w || xr0 < 0 || xr0 + 21 > G.w) continue;
+        const uint8_t* imL = pv.left + (long long)frame * pv.frameStride + G.off;
+        const uint8_t* imR = pv.right + (long long)frame * pv.frameStride + G.off;
+        const int xla = xl0 & ~3, xra = xr0 & ~3;
+        // 11 x 4 dwords of the left patch and 11 x 7 dwords of the right strip, one load per lane and pass
+        for (int i = lane; i < 11 * 4 + 11 * 7; i += 64) {
+            if (i < 44) {
+                const int r = i >> 2, d = i & 3;
+                patch[i] = *reinterpret_cast<const uint32_t*>(imL + (long long)(y0 + r) * G.pitch + xla + 4 * d);
+            } else {
+                const int t = i - 44, r = t / 7, d = t - r * 7;
+                patch[44 + r * 8 + d] = *reinterpret_cast<const uint32_t*>(imR + (long long)(y0 + r) * G.pitch + xra + 4 * d);
+            }
         }
-        depth[rowL] = __fdiv_rn(mbf, disparity);
-        uRight[rowL] = bestuR;
-        sadOut[rowL] = bestSad;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // item = (row dy, shift s): SAD of 11 pixels = three v_sad_u8 over byte windows
+        const int shL = xl0 - xla, offR = xr0 - xra;
+        for (int p = lane; p < 121; p += 64) {
+            const int dy = p / 11, sft = p - dy * 11;
+            const uint32_t* lp = patch + dy * 4;
+            const uint32_t a0 = __builtin_amdgcn_alignbyte(lp[1], lp[0], shL), a1 = __builtin_amdgcn_alignbyte(lp[2], lp[1], shL);
+            const uint32_t a2 = __builtin_amdgcn_alignbyte(lp[3], lp[2], shL) & 0x00FFFFFFu;
+            const int sb = offR + sft;
+            const uint32_t* rp = patch + 44 + dy * 8 + (sb >> 2);
+            const int sh = sb & 3;
+            const uint32_t b0 = __builtin_amdgcn_alignbyte(rp[1], rp[0], sh), b1 = __builtin_amdgcn_alignbyte(rp[2], rp[1], sh);
+            const uint32_t b2 = __builtin_amdgcn_alignbyte(rp[3], rp[2], sh) & 0x00FFFFFFu;
+            part[p] = (int)__builtin_amdgcn_sad_u8(a2, b2, __builtin_amdgcn_sad_u8(a1, b1, __builtin_amdgcn_sad_u8(a0, b0, 0u)));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        int mine = 0;
+        if (lane < 11) {
+#pragma unroll
+            for (int dy = 0; dy < 11; ++dy) mine += part[dy * 11 + lane];
+        }
+        int sad[11];
+#pragma unroll
+        for (int sft = 0; sft < 11; ++sft) sad[sft] = __shfl(mine, sft);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // patch / part are reused by the next keypoint
+        if (lane != 0) continue;
+        int bestSad = INT_MAX, bestInc = 0;
+#pragma unroll
+        for (int sft = 0; sft < 11; ++sft)
+            if (sad[sft] < bestSad) { bestSad = sad[sft]; bestInc = sft - L; }
+        if (bestInc == -L || bestInc == L) continue;
+        float d1 = 0.f, d2 = 0.f, d3 = 0.f;
+#pragma unroll
+        for (int sft = 1; sft < 10; ++sft)
+            if (sft - L == bestInc) { d1 = (float)sad[sft - 1]; d2 = (float)sad[sft]; d3 = (float)sad[sft + 1]; }
+        const float delta = __fdiv_rn(__fsub_rn(d1, d3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+        if (delta < -1 || delta > 1) continue;
+        float bestuR = __fmul_rn(G.scale, __fadd_rn(__fadd_rn(suR0, (float)bestInc), delta));
+        float disparity = __fsub_rn(uL, bestuR);
+        if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) {
+                disparity = 0.01f;                              // float(0.01)
+                bestuR = (float)((double)uL - 0.01);            // uL - 0.01 in double, then to float
+            }
+            depth[rowL] = __fdiv_rn(mbf, disparity);
+            uRight[rowL] = bestuR;
+            sadOut[rowL] = bestSad;
+        }
     }
 }
 
@@ -466,7 +577,8 @@ extern "C" orbx_status orbx_stereo_match_batch_device(orbx_extractor* left, orbx
     pv.frameStride = gl->pyrBytes;
     int* d_sad = (int*)orbx_internal_scratch(left, (size_t)n_frames * capacity * sizeof(int));
     if (!d_sad) { orbx_set_error("cannot allocate the SAD scratch buffer"); return ORBX_ERR_HIP; }
-    hipLaunchKernelGGL(k_stereo_rows, dim3((capacity + 3) / 4, n_frames), dim3(256), 0, st, orbx_internal_geo_device(left), pv,
+    hipLaunchKernelGGL(k_stereo_rows, dim3((capacity + kStWaves * kStPerWave - 1) / (kStWaves * kStPerWave), n_frames),
+                       dim3(64 * kStWaves), 0, st, orbx_internal_geo_device(left), pv,
                        d_kps_left, (const uint32_t*)d_desc_left, d_counts_left, d_kps_right, (const uint32_t*)d_desc_right,
                        d_counts_right, capacity, mbf, mb, d_u_right, d_depth, d_sad);
     hipLaunchKernelGGL(k_stereo_median, dim3(n_frames), dim3(256), 0, st, d_counts_left, capacity, d_u_right, d_depth, d_sad);
