@@ -209,6 +209,15 @@ def main():
     for l in range(NLEVELS):
         n_cand += len(exL.debug_level_candidates(l, 0)[0])
     fast_bytes = B * (px + 16 * n_cand)
+    # HBM-side traffic of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
+    # command, committed under profiles/ (FETCH_SIZE doubled: gfx950 tallies 128-byte reads as 64 bytes)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            t = json.load(f)
+        traffic = (t["fetch_correction"] * t["fetch_size_bytes_raw"] + t["write_size_bytes"]) * B / t["frames_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     fast_s = stage_ms["fast"] * 1e-3
     achieved = fast_bytes / fast_s / 1e9 if fast_s > 0 else 0.0
     frame_bytes = W * H + px + 60 * n_kp                                   # input + pyramid + keypoints/descriptors
@@ -224,7 +233,7 @@ def main():
                    "pairs_per_step_per_gpu": B, "frames_per_step": frames_per_step,
                    "keypoints_per_frame": n_kp, "stereo_matches_frame0": n_match, "parallelism": f"frames sharded x{world}"},
         "roofline": {"bound": "hbm", "kernel": "k_fast", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": fast_bytes, "avg_launch_ms": stage_ms["fast"],
                      "dominant_stage": dominant},
         "path_roofline": {"bound": "hbm", "bytes_per_frame": frame_bytes, "achieved": path_achieved, "peak": HBM_PEAK_GBS,
