@@ -72,7 +72,7 @@ extern "C" orbx_status orbx_descriptor_distance(const uint8_t* a, const uint8_t*
 // ======================================================================================
 constexpr int kQpl = 4;        // queries per lane
 constexpr int kKnnWaves = 4;
-constexpr int kRowsPerIter = 4;   // train rows fetched (scalar) and applied per loop trip
+constexpr int kRowsPerIter = 8;   // train rows fetched (scalar) and applied per loop trip
 
 // Per-query register state.  Four named instances (not an array) so that everything stays in
 // VGPRs: a runtime-indexed array of these would be placed in scratch memory.
@@ -98,22 +98,49 @@ __device__ __forceinline__ void knn_update(KnnQuery& s, int d, int gj) {
     }
 }
 
+// 8 x (v_xor_b32 + v_bcnt_u32_b32 with its accumulator operand) = 16 instructions per pair.  Written
+// with the instruction itself: left to the compiler, the eight counts are summed with three extra
+// v_add3_u32 per pair.
 __device__ __forceinline__ int knn_dist(const KnnQuery& s, const uint32_t (&t)[8]) {
-    int acc = 0;
+    uint32_t acc;
+    {
+        const uint32_t x = s.q[0] ^ t[0];
+        asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(acc) : "v"(x));
+    }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc += __popc(s.q[k] ^ t[k]);
-    return acc;
+    for (int k = 1; k < 8; ++k) {
+        const uint32_t x = s.q[k] ^ t[k];
+        asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "v"(x));
+    }
+    return (int)acc;
 }
 
-// kRowsPerIter (= 4) rows against one query: the bookkeeping is entered only when the smallest
-// of the four distances beats the current second best, and then replays the rows in
+// kRowsPerIter (= 8) rows against one query: the bookkeeping is entered only when the smallest
+// of the eight distances beats the current second best, and then replays the rows in
 // ascending index order (strict '<' keeps the lowest index among equal distances).
-__device__ __forceinline__ void knn_rows4(KnnQuery& s, const uint32_t (&t0)[8], const uint32_t (&t1)[8],
-                                          const uint32_t (&t2)[8], const uint32_t (&t3)[8], int gj) {
-    const int d0 = knn_dist(s, t0), d1 = knn_dist(s, t1), d2 = knn_dist(s, t2), d3 = knn_dist(s, t3);
-    const int m = min(min(d0, d1), min(d2, d3));
+__device__ __forceinline__ void knn_rows8(KnnQuery& s, const uint32_t (&t)[8][8], int gj) {
+    // the eight accumulator chains advance together, word by word
+    uint32_t acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const uint32_t x = s.q[0] ^ t[r][0];
+        asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(acc[r]) : "v"(x));
+    }
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t x = s.q[k] ^ t[r][k];
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[r]) : "v"(x));
+        }
+    }
+    int d[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d[r] = (int)acc[r];
+    const int m = min(min(min(d[0], d[1]), min(d[2], d[3])), min(min(d[4], d[5]), min(d[6], d[7])));
     if (m < s.second) {
-        knn_update(s, d0, gj); knn_update(s, d1, gj + 1); knn_update(s, d2, gj + 2); knn_update(s, d3, gj + 3);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) knn_update(s, d[r], gj + r);
     }
 }
 
@@ -129,7 +156,7 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restr
                                                           const uint32_t* __restrict__ train, long long nt,
                                                           long long chunkLen, long long baseIndex,
                                                           orbx_match2* __restrict__ part) {
-    static_assert(kQpl == 4 && kRowsPerIter == 4, "the body below is written out for 4 x 4");
+    static_assert(kQpl == 4 && kRowsPerIter == 8, "the body below is written out for 4 queries x 8 rows");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int group = blockIdx.x * kKnnWaves + wave;
@@ -147,14 +174,16 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restr
     long long j = j0;
     for (; j + kRowsPerIter <= j1; j += kRowsPerIter) {
         const uint32_t* __restrict__ t = train + 8ll * j;   // wave-uniform: scalar loads
-        uint32_t t0[8], t1[8], t2[8], t3[8];
+        uint32_t tr[8][8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { t0[k] = t[k]; t1[k] = t[8 + k]; t2[k] = t[16 + k]; t3[k] = t[24 + k]; }
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tr[r][k] = t[8 * r + k];
         const int gj = (int)(baseIndex + j);
-        knn_rows4(a, t0, t1, t2, t3, gj);
-        knn_rows4(b, t0, t1, t2, t3, gj);
-        knn_rows4(c, t0, t1, t2, t3, gj);
-        knn_rows4(d, t0, t1, t2, t3, gj);
+        knn_rows8(a, tr, gj);
+        knn_rows8(b, tr, gj);
+        knn_rows8(c, tr, gj);
+        knn_rows8(d, tr, gj);
     }
     for (; j < j1; ++j) {
         const uint32_t* __restrict__ t = train + 8ll * j;
