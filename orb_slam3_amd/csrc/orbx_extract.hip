@@ -912,7 +912,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
                                                               orbx_keypoint* __restrict__ outKps,
                                                               uint8_t* __restrict__ outDesc, int capacity) {
     __shared__ __align__(16) uint8_t s_raw[kDescWaves][kRawW * kRawP];    // raw patch, later the blurred core
-    __shared__ __align__(16) uint16_t s_hor[kDescWaves][kRawW * kBlurP];
+    __shared__ __align__(16) uint16_t s_hor[kDescWaves][40 * 44];     // transposed row sums: 40 columns x 44 rows
     __shared__ uint2 s_orientW[128];
     if (threadIdx.x < 128) s_orientW[threadIdx.x] = make_uint2(c_orientW.w[2 * threadIdx.x], c_orientW.w[2 * threadIdx.x + 1]);
 
@@ -1005,6 +1005,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     constexpr int kHorTP = 44;                       // rows per column of horT (even)
     const uint32_t wLo = 18u | (34u << 8) | (48u << 16) | (56u << 24);
     const uint32_t wHi = 48u | (34u << 8) | (18u << 16);
+    // All 8 outputs of an item are stored (columns 37..39 and rows 37..39 are padding that nothing
+    // reads), so the stores are unconditional and their addresses differ by compile-time constants.
     for (int i = lane; active && i < kRawW * 5; i += 64) {
         const int r = i / 5, c0 = (i - r * 5) * 8;
         const int b0 = ox + c0;
@@ -1014,14 +1016,17 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
         uint32_t W[4];
         W[0] = __builtin_amdgcn_alignbyte(d1, d0, sh); W[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
         W[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); W[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
+        // byte windows A[k] = bytes k .. k+3 of the 16-byte window, k = 0 .. 11
+        uint32_t A[12];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint32_t lo4 = (k & 3) ? __builtin_amdgcn_alignbyte(W[(k >> 2) + 1], W[k >> 2], k & 3) : W[k >> 2];
-            const uint32_t hi4 = (k & 3) ? __builtin_amdgcn_alignbyte(W[(k >> 2) + 2 > 3 ? 3 : (k >> 2) + 2], W[(k >> 2) + 1], k & 3)
-                                         : W[(k >> 2) + 1];
-            const uint32_t h = __builtin_amdgcn_udot4(hi4, wHi, __builtin_amdgcn_udot4(lo4, wLo, 0u, false), false);
-            if (c0 + k < kBlurW) hor[(c0 + k) * kHorTP + r] = (uint16_t)h;
-        }
+        for (int k = 0; k < 12; ++k)
+            A[k] = (k & 3) ? __builtin_amdgcn_alignbyte(W[(k >> 2) + 1], W[k >> 2], k & 3) : W[k >> 2];
+        uint32_t lo[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lo[k] = __builtin_amdgcn_udot4(A[k], wLo, 0u, false);
+        uint16_t* dst = hor + c0 * kHorTP + r;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k * kHorTP] = (uint16_t)__builtin_amdgcn_udot4(A[k + 4], wHi, lo[k], false);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
     // vertical: item = (column c, 8 output rows r0..r0+7): 14 row sums = 7 packed pairs, four
@@ -1034,19 +1039,18 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
         for (int m = 0; m < 7; ++m) Hh[m] = __builtin_bit_cast(us2, colp[m]);
         const us2 e0 = {18, 34}, e1 = {48, 56}, e2 = {48, 34}, e3 = {18, 0};      // even rows: taps 0..6 from the pair start
         const us2 o0 = {0, 18}, o1 = {34, 48}, o2 = {56, 48}, o3 = {34, 18};      // odd rows: one tap later
+        uint32_t sum[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int j = k >> 1;
-            uint32_t sum = 32768u;
-            if (k & 1) {
-                sum = __builtin_amdgcn_udot2(Hh[j], o0, sum, false);     sum = __builtin_amdgcn_udot2(Hh[j + 1], o1, sum, false);
-                sum = __builtin_amdgcn_udot2(Hh[j + 2], o2, sum, false); sum = __builtin_amdgcn_udot2(Hh[j + 3], o3, sum, false);
-            } else {
-                sum = __builtin_amdgcn_udot2(Hh[j], e0, sum, false);     sum = __builtin_amdgcn_udot2(Hh[j + 1], e1, sum, false);
-                sum = __builtin_amdgcn_udot2(Hh[j + 2], e2, sum, false); sum = __builtin_amdgcn_udot2(Hh[j + 3], e3, sum, false);
-            }
-            if (r0 + k < kBlurW) blur[(r0 + k) * kBlurP + c] = (uint8_t)(sum >> 16);
-        }
+        for (int k = 0; k < 8; ++k) sum[k] = __builtin_amdgcn_udot2(Hh[k >> 1], (k & 1) ? o0 : e0, 32768u, false);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum[k] = __builtin_amdgcn_udot2(Hh[(k >> 1) + 1], (k & 1) ? o1 : e1, sum[k], false);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum[k] = __builtin_amdgcn_udot2(Hh[(k >> 1) + 2], (k & 1) ? o2 : e2, sum[k], false);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum[k] = __builtin_amdgcn_udot2(Hh[(k >> 1) + 3], (k & 1) ? o3 : e3, sum[k], false);
+        uint8_t* dst = blur + r0 * kBlurP + c;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dst[k * kBlurP] = (uint8_t)(sum[k] >> 16);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
 
