@@ -910,7 +910,8 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
                                                               const OrbxLevelKp* __restrict__ levelKps,
                                                               const int* __restrict__ kpCount,
                                                               orbx_keypoint* __restrict__ outKps,
-                                                              uint8_t* __restrict__ outDesc, int capacity) {
+                                                              uint8_t* __restrict__ outDesc, int capacity,
+                                                              const uint8_t* __restrict__ kpLevel) {
     __shared__ __align__(16) uint8_t s_raw[kDescWaves][kRawW * kRawP];    // raw patch, later the blurred core
     __shared__ __align__(16) uint16_t s_hor[kDescWaves][40 * 44];     // transposed row sums: 40 columns x 44 rows
     __shared__ uint2 s_orientW[128];
@@ -919,13 +920,14 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     // keypoints of one frame read the same few level images: keep a frame on one XCD
     const int logicalBlock = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int frame = logicalBlock / gridDim.x;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ordinal = (logicalBlock - frame * gridDim.x) * kDescWaves + wv;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int ordinal = (logicalBlock - frame * gridDim.x) * kDescWaves + wv;   // wave-uniform
     const int nl = geo->nlevels;
+    // level of the keypoint record `ordinal` of a frame: host-built byte table
     int level = -1, idx = 0;
-    for (int l = 0; l < nl; ++l) {
-        const int o = ordinal - geo->lv[l].kpOff;
-        if (o >= 0 && o < geo->lv[l].kpCap) { level = l; idx = o; }
+    if (ordinal < geo->kpTotal) {
+        level = kpLevel[ordinal];
+        idx = ordinal - geo->lv[level].kpOff;
     }
     // Waves without a keypoint stay in step (they only skip the work) so that every
     // wave of the workgroup reaches the barrier below.
@@ -1118,6 +1120,7 @@ struct orbx_extractor {
     OrbxErr* h_err = nullptr;      // pinned
     orbx_rect* d_rects = nullptr;
     int4* d_cells = nullptr;       // FAST cell table
+    uint8_t* d_kpLevel = nullptr;  // level of each keypoint record of a frame
     int *d_xofs = nullptr, *d_yofs = nullptr;
     uint32_t *d_xcoef = nullptr, *d_ycoef = nullptr;
     size_t tapAlloc = 0;
@@ -1192,6 +1195,7 @@ static void free_geo_buffers(orbx_extractor* ex) {
     hipFree(ex->d_xcoef); ex->d_xcoef = nullptr;
     hipFree(ex->d_ycoef); ex->d_ycoef = nullptr;
     hipFree(ex->d_cells); ex->d_cells = nullptr;
+    hipFree(ex->d_kpLevel); ex->d_kpLevel = nullptr;
 }
 
 // Computes the level / cell / quadtree geometry for a w x h image and (re)allocates the
@@ -1314,6 +1318,12 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
         }
         ORBX_HIP_TRY(hipMalloc((void**)&ex->d_cells, cells.size() * sizeof(int4)));
         ORBX_HIP_TRY(hipMemcpy(ex->d_cells, cells.data(), cells.size() * sizeof(int4), hipMemcpyHostToDevice));
+        // level of every keypoint record of a frame (describe kernel)
+        std::vector<uint8_t> kpLevel(std::max(g.kpTotal, 1), 0);
+        for (int l = 0; l < P.nlevels; ++l)
+            for (int i = 0; i < g.lv[l].kpCap; ++i) kpLevel[g.lv[l].kpOff + i] = (uint8_t)l;
+        ORBX_HIP_TRY(hipMalloc((void**)&ex->d_kpLevel, kpLevel.size()));
+        ORBX_HIP_TRY(hipMemcpy(ex->d_kpLevel, kpLevel.data(), kpLevel.size(), hipMemcpyHostToDevice));
     }
     ORBX_HIP_TRY(hipMemcpy(ex->d_geo, &g, sizeof(g), hipMemcpyHostToDevice));
     ex->geoValid = true;
@@ -1450,7 +1460,8 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
                        capacity, d_counts, ex->d_err);
     mark(ex, st);
     hipLaunchKernelGGL(k_describe, dim3((g.kpTotal + kDescWaves - 1) / kDescWaves, nf), dim3(64 * kDescWaves), 0, st,
-                       ex->d_geo, ex->d_pyr, g.pyrBytes, ex->d_levelKps, ex->d_kpCount, d_kps, d_desc, capacity);
+                       ex->d_geo, ex->d_pyr, g.pyrBytes, ex->d_levelKps, ex->d_kpCount, d_kps, d_desc, capacity,
+                       ex->d_kpLevel);
     mark(ex, st);
     ORBX_HIP_TRY(hipGetLastError());
     ex->lastFrames = nf;
