@@ -1131,6 +1131,11 @@ struct orbx_extractor {
     int outCap = 0;
     int lastFrames = 0;
     void* d_scratch = nullptr;     size_t scratchAlloc = 0;
+    // pinned / device staging of the host entry points
+    uint8_t* h_in = nullptr;       uint8_t* d_in = nullptr;   size_t stageInBytes = 0;
+    orbx_keypoint* h_outKps = nullptr;
+    uint8_t* h_outDesc = nullptr;
+    int* h_counts = nullptr;
     // optional per-kernel timing (hipEvents on the launch stream)
     bool timing = false;
     std::vector<hipEvent_t> evPool;          // kTimedStages + 1 events per recorded batch
@@ -1393,6 +1398,11 @@ extern "C" void orbx_extractor_destroy(orbx_extractor* ex) {
     hipFree(ex->d_geo); hipFree(ex->d_candCount); hipFree(ex->d_kpCount); hipFree(ex->d_err);
     hipFree(ex->d_rects); hipFree(ex->d_scratch); hipFree(ex->d_outKps); hipFree(ex->d_outDesc); hipFree(ex->d_counts);
     if (ex->h_err) hipHostFree(ex->h_err);
+    if (ex->h_in) hipHostFree(ex->h_in);
+    if (ex->d_in) hipFree(ex->d_in);
+    if (ex->h_outKps) hipHostFree(ex->h_outKps);
+    if (ex->h_outDesc) hipHostFree(ex->h_outDesc);
+    if (ex->h_counts) hipHostFree(ex->h_counts);
     delete ex;
 }
 
@@ -1516,6 +1526,72 @@ extern "C" orbx_status orbx_extract_status(orbx_extractor* ex) {
     return ORBX_OK;
 }
 
+// Host entry points: images are packed into a pinned staging buffer, uploaded with one linear copy,
+// run through the device path, and the result arrays come back with three linear copies into pinned
+// memory.  (Row-pitched copies straight from pageable memory cost milliseconds per image.)
+static orbx_status ensure_host_staging(orbx_extractor* ex) {
+    const size_t inBytes = (size_t)ex->prm.max_batch * ex->prm.max_width * ex->prm.max_height;
+    const size_t B = (size_t)ex->prm.max_batch;
+    if (ex->h_in && ex->stageInBytes >= inBytes) return ORBX_OK;
+    if (ex->h_in) { hipHostFree(ex->h_in); ex->h_in = nullptr; }
+    if (ex->d_in) { hipFree(ex->d_in); ex->d_in = nullptr; }
+    if (ex->h_outKps) { hipHostFree(ex->h_outKps); ex->h_outKps = nullptr; }
+    if (ex->h_outDesc) { hipHostFree(ex->h_outDesc); ex->h_outDesc = nullptr; }
+    if (ex->h_counts) { hipHostFree(ex->h_counts); ex->h_counts = nullptr; }
+    ORBX_HIP_TRY(hipHostMalloc((void**)&ex->h_in, inBytes));
+    ORBX_HIP_TRY(hipMalloc((void**)&ex->d_in, inBytes + 16));
+    ORBX_HIP_TRY(hipHostMalloc((void**)&ex->h_outKps, B * ex->outCap * sizeof(orbx_keypoint)));
+    ORBX_HIP_TRY(hipHostMalloc((void**)&ex->h_outDesc, B * ex->outCap * 32));
+    ORBX_HIP_TRY(hipHostMalloc((void**)&ex->h_counts, B * 2 * sizeof(int)));
+    ex->stageInBytes = inBytes;
+    return ORBX_OK;
+}
+
+static orbx_status extract_host(orbx_extractor* ex, const uint8_t* const* images, int n_frames, int width, int height,
+                                ptrdiff_t stride, int lap0, int lap1, const orbx_rect* dyn, int ndyn,
+                                orbx_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_out,
+                                int* mono_index_out) {
+    ORBX_HIP_TRY(hipSetDevice(ex->device));
+    orbx_status s = ensure_geometry(ex, width, height);
+    if (s != ORBX_OK) return s;
+    s = ensure_host_staging(ex);
+    if (s != ORBX_OK) return s;
+    const size_t frameBytes = (size_t)width * height;
+    for (int f = 0; f < n_frames; ++f) {
+        if (!images[f]) { orbx_set_error("empty image"); return ORBX_ERR_EMPTY; }
+        uint8_t* dst = ex->h_in + (size_t)f * frameBytes;
+        if (stride == width) memcpy(dst, images[f], frameBytes);
+        else for (int y = 0; y < height; ++y) memcpy(dst + (size_t)y * width, images[f] + (ptrdiff_t)y * stride, width);
+    }
+    const size_t B = (size_t)n_frames;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        ORBX_HIP_TRY(hipMemcpyAsync(ex->d_in, ex->h_in, B * frameBytes, hipMemcpyHostToDevice, ex->stream));
+        s = orbx_extract_batch_device(ex, ex->d_in, n_frames, width, height, width, (ptrdiff_t)frameBytes, lap0, lap1, dyn,
+                                      ndyn, ex->d_outKps, ex->d_outDesc, ex->outCap, ex->d_counts, ex->stream);
+        if (s != ORBX_OK) return s;
+        ORBX_HIP_TRY(hipMemcpyAsync(ex->h_counts, ex->d_counts, B * 2 * sizeof(int), hipMemcpyDeviceToHost, ex->stream));
+        ORBX_HIP_TRY(hipMemcpyAsync(ex->h_outKps, ex->d_outKps, B * ex->outCap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, ex->stream));
+        ORBX_HIP_TRY(hipMemcpyAsync(ex->h_outDesc, ex->d_outDesc, B * ex->outCap * 32, hipMemcpyDeviceToHost, ex->stream));
+        ORBX_HIP_TRY(hipStreamSynchronize(ex->stream));
+        s = orbx_extract_status(ex);
+        if (s == ORBX_ERR_CAPACITY && ex->h_err->cand_overflow) continue;   // regrown: run again
+        break;
+    }
+    if (s != ORBX_OK) return s;
+    for (int f = 0; f < n_frames; ++f) {
+        const int n = ex->h_counts[2 * f];
+        n_out[f] = n;
+        mono_index_out[f] = ex->h_counts[2 * f + 1];
+        if (n > capacity) { orbx_set_error("frame %d has %d keypoints, capacity is %d", f, n, capacity); return ORBX_ERR_CAPACITY; }
+        if (n > 0) {
+            ORBX_REQUIRE(keypoints && descriptors, "null output buffer");
+            memcpy(keypoints + (size_t)f * capacity, ex->h_outKps + (size_t)f * ex->outCap, n * sizeof(orbx_keypoint));
+            memcpy(descriptors + (size_t)f * capacity * 32, ex->h_outDesc + (size_t)f * ex->outCap * 32, (size_t)n * 32);
+        }
+    }
+    return ORBX_OK;
+}
+
 extern "C" orbx_status orbx_extract_batch(orbx_extractor* ex, const uint8_t* const* images, int n_frames, int width,
                                           int height, ptrdiff_t stride, int lap0, int lap1, orbx_keypoint* keypoints,
                                           uint8_t* descriptors, int capacity, int* n_out, int* mono_index_out) {
@@ -1523,43 +1599,8 @@ extern "C" orbx_status orbx_extract_batch(orbx_extractor* ex, const uint8_t* con
     ORBX_REQUIRE(n_frames >= 1 && n_frames <= ex->prm.max_batch, "n_frames %d outside [1, %d]", n_frames, ex->prm.max_batch);
     if (width <= 0 || height <= 0) { orbx_set_error("empty image"); return ORBX_ERR_EMPTY; }
     ORBX_REQUIRE(stride >= width, "stride smaller than width");
-    ORBX_HIP_TRY(hipSetDevice(ex->device));
-    orbx_status s = ensure_geometry(ex, width, height);
-    if (s != ORBX_OK) return s;
-    const OrbxLevelGeo& L0 = ex->geo.lv[0];
-    for (int attempt = 0; attempt < 8; ++attempt) {
-        mark(ex, ex->stream);
-        for (int f = 0; f < n_frames; ++f) {
-            if (!images[f]) { orbx_set_error("empty image"); return ORBX_ERR_EMPTY; }
-            ORBX_HIP_TRY(hipMemcpy2DAsync(ex->d_pyr + (size_t)f * ex->geo.pyrBytes + L0.off, L0.pitch, images[f], stride,
-                                          width, height, hipMemcpyHostToDevice, ex->stream));
-        }
-        s = enqueue_batch(ex, n_frames, lap0, lap1, nullptr, 0, ex->d_outKps, ex->d_outDesc, ex->outCap, ex->d_counts,
-                          ex->stream);
-        if (s != ORBX_OK) return s;
-        ORBX_HIP_TRY(hipStreamSynchronize(ex->stream));
-        s = orbx_extract_status(ex);
-        if (s == ORBX_ERR_CAPACITY && ex->h_err->cand_overflow) continue;   // regrown: run again
-        if (s != ORBX_OK) return s;
-        break;
-    }
-    if (s != ORBX_OK) return s;
-    std::vector<int> counts(2 * (size_t)n_frames);
-    ORBX_HIP_TRY(hipMemcpy(counts.data(), ex->d_counts, counts.size() * sizeof(int), hipMemcpyDeviceToHost));
-    for (int f = 0; f < n_frames; ++f) {
-        const int n = counts[2 * f];
-        n_out[f] = n;
-        mono_index_out[f] = counts[2 * f + 1];
-        if (n > capacity) { orbx_set_error("frame %d has %d keypoints, capacity is %d", f, n, capacity); return ORBX_ERR_CAPACITY; }
-        if (n > 0) {
-            ORBX_REQUIRE(keypoints && descriptors, "null output buffer");
-            ORBX_HIP_TRY(hipMemcpy(keypoints + (size_t)f * capacity, ex->d_outKps + (size_t)f * ex->outCap,
-                                   n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
-            ORBX_HIP_TRY(hipMemcpy(descriptors + (size_t)f * capacity * 32, ex->d_outDesc + (size_t)f * ex->outCap * 32,
-                                   (size_t)n * 32, hipMemcpyDeviceToHost));
-        }
-    }
-    return ORBX_OK;
+    return extract_host(ex, images, n_frames, width, height, stride, lap0, lap1, nullptr, 0, keypoints, descriptors, capacity,
+                        n_out, mono_index_out);
 }
 
 extern "C" orbx_status orbx_extract(orbx_extractor* ex, const uint8_t* image, int width, int height, ptrdiff_t stride,
@@ -1571,37 +1612,10 @@ extern "C" orbx_status orbx_extract(orbx_extractor* ex, const uint8_t* image, in
         *n_out = 0; *mono_index_out = -1;
         return ORBX_ERR_EMPTY;
     }
-    if (ndyn == 0) return orbx_extract_batch(ex, &image, 1, width, height, stride, lap0, lap1, keypoints, descriptors,
-                                             capacity, n_out, mono_index_out);
-    // with dynamic rectangles: same path, rectangles uploaded per call
     ORBX_REQUIRE(stride >= width, "stride smaller than width");
-    ORBX_REQUIRE(dyn && ndyn > 0 && ndyn <= kOrbxMaxRects, "bad rectangle list");
-    ORBX_HIP_TRY(hipSetDevice(ex->device));
-    orbx_status s = ensure_geometry(ex, width, height);
-    if (s != ORBX_OK) return s;
-    const OrbxLevelGeo& L0 = ex->geo.lv[0];
-    for (int attempt = 0; attempt < 8; ++attempt) {
-        mark(ex, ex->stream);
-        ORBX_HIP_TRY(hipMemcpy2DAsync(ex->d_pyr + L0.off, L0.pitch, image, stride, width, height, hipMemcpyHostToDevice,
-                                      ex->stream));
-        s = enqueue_batch(ex, 1, lap0, lap1, dyn, ndyn, ex->d_outKps, ex->d_outDesc, ex->outCap, ex->d_counts, ex->stream);
-        if (s != ORBX_OK) return s;
-        ORBX_HIP_TRY(hipStreamSynchronize(ex->stream));
-        s = orbx_extract_status(ex);
-        if (s == ORBX_ERR_CAPACITY && ex->h_err->cand_overflow) continue;
-        break;
-    }
-    if (s != ORBX_OK) return s;
-    int counts[2];
-    ORBX_HIP_TRY(hipMemcpy(counts, ex->d_counts, sizeof(counts), hipMemcpyDeviceToHost));
-    *n_out = counts[0]; *mono_index_out = counts[1];
-    if (counts[0] > capacity) { orbx_set_error("%d keypoints, capacity is %d", counts[0], capacity); return ORBX_ERR_CAPACITY; }
-    if (counts[0] > 0) {
-        ORBX_REQUIRE(keypoints && descriptors, "null output buffer");
-        ORBX_HIP_TRY(hipMemcpy(keypoints, ex->d_outKps, counts[0] * sizeof(orbx_keypoint), hipMemcpyDeviceToHost));
-        ORBX_HIP_TRY(hipMemcpy(descriptors, ex->d_outDesc, (size_t)counts[0] * 32, hipMemcpyDeviceToHost));
-    }
-    return ORBX_OK;
+    ORBX_REQUIRE(ndyn == 0 || (dyn && ndyn > 0 && ndyn <= kOrbxMaxRects), "bad rectangle list");
+    return extract_host(ex, &image, 1, width, height, stride, lap0, lap1, dyn, ndyn, keypoints, descriptors, capacity, n_out,
+                        mono_index_out);
 }
 
 extern "C" orbx_status orbx_extractor_set_timing(orbx_extractor* ex, int enable) {
