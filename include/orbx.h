@@ -164,6 +164,11 @@ orbx_status orbx_debug_wave_sort(const uint64_t* elems, const int* offsets, int 
 
 /* ---------------------------------------------------------------- matcher ---------- */
 
+/* The synchronous matcher entry points below keep their temporary device blocks in a per-thread
+ * cache (at most 2 GiB) instead of freeing them; this returns the calling thread's cache to the
+ * device.  No counterpart in the reference. */
+void orbx_release_cached_memory(void);
+
 /* ORBmatcher::DescriptorDistance (ORBmatcher.cc:2141-2157) for n pairs: out[i] =
  * popcount(a[i] xor b[i]) over 256 bits.  Host pointers. */
 orbx_status orbx_descriptor_distance(const uint8_t* a, const uint8_t* b, int n, int* out);

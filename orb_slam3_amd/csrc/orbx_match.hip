@@ -21,13 +21,56 @@
 // small RAII helper for the synchronous host entry points
 // --------------------------------------------------------------------------------------
 namespace {
+// Device blocks of the synchronous entry points are recycled per host thread: the matchers are called
+// many times per frame and a hipMalloc / hipFree pair per temporary costs more than the kernels.
+// Blocks are rounded up to powers of two and kept until orbx_release_cached_memory() (or process end).
+struct DevBlockCache {
+    struct Block { void* p; size_t cap; int device; };
+    std::vector<Block> free;
+    size_t cachedBytes = 0;
+};
+thread_local DevBlockCache t_cache;
+constexpr size_t kCacheLimit = (size_t)2 << 30;
+
 struct DevBuf {
     void* p = nullptr;
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
-    ~DevBuf() { if (p) hipFree(p); }
+    size_t cap = 0;
+    int device = 0;
+    hipError_t alloc(size_t bytes) {
+        size_t want = 4096;
+        while (want < bytes) want <<= 1;
+        hipError_t e = hipGetDevice(&device);
+        if (e != hipSuccess) return e;
+        auto& f = t_cache.free;
+        for (size_t i = 0; i < f.size(); ++i)
+            if (f[i].cap == want && f[i].device == device) {
+                p = f[i].p; cap = want;
+                t_cache.cachedBytes -= want;
+                f[i] = f.back(); f.pop_back();
+                return hipSuccess;
+            }
+        e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want; else p = nullptr;
+        return e;
+    }
+    ~DevBuf() {
+        if (!p) return;
+        if (t_cache.cachedBytes + cap <= kCacheLimit) {
+            t_cache.free.push_back({p, cap, device});
+            t_cache.cachedBytes += cap;
+        } else {
+            (void)hipFree(p);
+        }
+    }
     template <class T> T* as() { return static_cast<T*>(p); }
 };
 }  // namespace
+
+extern "C" void orbx_release_cached_memory(void) {
+    for (auto& b : t_cache.free) (void)hipFree(b.p);
+    t_cache.free.clear();
+    t_cache.cachedBytes = 0;
+}
 
 __device__ __forceinline__ int hamming256(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b) {
     int d = 0;

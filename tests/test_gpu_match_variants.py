@@ -278,3 +278,37 @@ def test_bucket_allpairs(oracle):
             exp = pop[d1[fv1[0][e]][None, :] ^ d2[js]].sum(1)
             assert np.array_equal(dist[rs[e]:rs[e] + len(js)], exp.astype(np.uint16))
     assert rs[-1] == len(dist)
+
+
+def test_empty_inputs():
+    """No queries, no keypoints, no shared vocabulary nodes: every entry point returns cleanly."""
+    A = _gpu()
+    rng = np.random.default_rng(12)
+    kps, desc = _frame(rng, 50, A)
+    m = A.ORBmatcher(0.9, True)
+    q0 = np.zeros(0, A.QUERY_DTYPE)
+    d0 = np.zeros((0, 32), np.uint8)
+    out, kpm, n = m.SearchWindowBest(kps, desc, None, BOUNDS, q0, d0, 100.0, np.zeros(50, np.uint8))
+    assert n == 0 and len(out) == 0 and np.all(kpm == -1)
+    q, _, _ = _queries(rng, A, kps, 10)
+    out, kpm, n = m.SearchWindowBest(kps[:0], d0, None, BOUNDS, q, desc[:10], 100.0, None)
+    assert n == 0 and np.all(out == -1) and len(kpm) == 0
+    out, n = m.Fuse(kps, desc, None, BOUNDS, q0, d0, np.ones(8, np.float32))
+    assert n == 0 and len(out) == 0
+    z = np.zeros(0, np.int32)
+    off0 = np.zeros(1, np.int32)
+    out, n = m.SearchByBoW(desc, kps["angle"], np.ones(50, np.uint8), (z, off0), desc, kps["angle"], (z, off0))
+    assert n == 0 and np.all(out == -1)
+    out, n = m.SearchByBoWKeyFrames(desc, kps["angle"], np.ones(50, np.uint8), (z, off0), desc, kps["angle"],
+                                    np.ones(50, np.uint8), (z, off0))
+    assert n == 0 and np.all(out == -1)
+    # nodes present but empty on one side
+    off = np.array([0, 3, 3], np.int32)
+    offe = np.array([0, 0, 2], np.int32)
+    out, n = m.SearchByBoWKeyFrames(desc, kps["angle"], np.ones(50, np.uint8), (np.array([0, 1, 2], np.int32), off), desc,
+                                    kps["angle"], np.ones(50, np.uint8), (np.array([4, 5], np.int32), offe))
+    assert n == 0 and np.all(out == -1)
+    prev = np.stack([kps["x"], kps["y"]], 1).astype(np.float32)
+    out, n = m.SearchForInitialization(kps, desc, kps[:0], d0, BOUNDS, prev, 100)
+    assert n == 0 and np.all(out == -1)
+    A.lib().orbx_release_cached_memory()

@@ -28,3 +28,25 @@ for B in (8, 32, 128):
         ex.extract_batch(batch, (0, 0))
     dt = time.perf_counter() - t0
     print(f"orbx_extract_batch, {B:3d} frames per call: {1e3 * dt / (reps * B):7.3f} ms per frame, {reps * B / dt:8.1f} frames/s")
+
+# matcher entry points (host arrays in and out): per-call latency
+rng = np.random.default_rng(3)
+k, d, _ = ex1(imgs[0], (0, 0))
+nq = 800
+src = rng.integers(0, len(k), nq)
+q = np.zeros(nq, A.QUERY_DTYPE)
+q["x"] = k["x"][src] + rng.normal(0, 3, nq); q["y"] = k["y"][src] + rng.normal(0, 3, nq)
+lvl = k["octave"][src]
+q["radius"] = 7 * (1.2 ** lvl); q["min_level"] = lvl - 1; q["max_level"] = lvl
+qd = d[src].copy()
+m = A.ORBmatcher(0.8)
+bounds = (0.0, float(W), 0.0, float(H))
+for name, fn in [("SearchByProjection (800 map points, 1000 keypoints)",
+                  lambda: m.SearchByProjection(k, d, None, bounds, q, qd, np.zeros(len(k), np.uint8))),
+                 ("SearchWindowBest + rotation check", lambda: m.SearchWindowBest(k, d, None, bounds, q, qd, 100.0, np.zeros(len(k), np.uint8), None, k["angle"][src])),
+                 ("knn_match2 1000 x 1000", lambda: A.knn_match2(d, d))]:
+    fn(); fn()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        fn()
+    print(f"{name:55s} {1e3 * (time.perf_counter() - t0) / 20:7.3f} ms per call")
