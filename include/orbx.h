@@ -363,6 +363,37 @@ orbx_status orbx_search_for_triangulation(const orbx_keypoint* kps1, const uint8
                                           const orbx_epipolar* geom, int only_stereo, int coarse, int check_orientation,
                                           int* matches12, int* n_matches);
 
+/* ---- bag-of-words transform (the step between extraction and the BoW matchers) ----------
+ * DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>::transform
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1112-1243; Frame::ComputeBoW, Frame.cc:872-879,
+ * KeyFrame::ComputeBoW, KeyFrame.cc:100-109, both with levelsup = 4).
+ * The vocabulary tree is handed over flattened: node 0 is the root, the children of node i are
+ * child_idx[child_off[i] .. child_off[i+1]) in the order of DBoW2's Node::children, every node has
+ * a 32-byte descriptor (the root's is ignored), leaves carry word_id >= 0 and their weight
+ * (idf for TF_IDF), inner nodes word_id = -1.  depth = m_L. */
+typedef struct orbx_vocabulary orbx_vocabulary;
+orbx_status orbx_vocabulary_create(int n_nodes, const int* child_off, const int* child_idx,
+                                   const uint8_t* node_descriptors, const int* word_id, const double* weight,
+                                   int depth, int device, orbx_vocabulary** out);
+void orbx_vocabulary_destroy(orbx_vocabulary* voc);
+
+/* transform(feature, word_id, weight, &nid, levelsup) for n descriptors: descent from the root,
+ * at every level the child with the smallest FORB::distance, the first among equals; node_id is
+ * the node passed at level depth - levelsup (the root when that is <= 0; also the root when the
+ * leaf lies above that level, where the reference leaves nid unset).  Host pointers. */
+orbx_status orbx_bow_transform(orbx_vocabulary* voc, const uint8_t* desc, int n, int levelsup,
+                               int* word_id, double* weight, int* node_id);
+
+/* transform(features, BowVector&, FeatureVector&, levelsup) for TF_IDF weighting: the BowVector as
+ * ascending (word, value) pairs (weights summed in feature order, then L1-normalised when
+ * l1_normalize != 0, else divided by the number of words as TemplatedVocabulary.h:1149-1155 does),
+ * the FeatureVector as CSR over ascending node ids: features fv_idx[fv_off[b] .. fv_off[b+1]) of
+ * node fv_node[b] in ascending feature order -- the layout orbx_search_by_bow* consume.  Outputs
+ * hold up to n entries (fv_off: n + 1). */
+orbx_status orbx_bow_vectors(orbx_vocabulary* voc, const uint8_t* desc, int n, int levelsup, int l1_normalize,
+                             int* bow_word, double* bow_value, int* n_bow,
+                             int* fv_node, int* fv_off, int* fv_idx, int* n_fv_nodes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,7 @@ def lib():
         L.orc_search_by_bow_keyframes.argtypes = ([C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_void_p]) * 2 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orc_search_for_triangulation.restype = C.c_int
         L.orc_search_for_triangulation.argtypes = ([C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p]) * 2 + [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_bow_transform.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3
         L.orc_search_by_projection.restype = C.c_int
         L.orc_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -413,3 +414,17 @@ def search_for_triangulation(kps1, desc1, free1, ur1, idx1, off1, kps2, desc2, f
                                            len(a[3]) - 1, _p(F), float(ep[0]), float(ep[1]), _p(sf), _p(sg),
                                            int(only_stereo), int(coarse), int(check_ori), _p(out))
     return out, n
+
+
+def bow_transform(child_off, child_idx, node_desc, word_id, weight, depth, desc, levelsup):
+    """Per descriptor (word id, weight, feature-vector node) of DBoW2's tree descent."""
+    co, ci = _i32(child_off), _i32(child_idx)
+    nd, wi = _u8(node_desc), _i32(word_id)
+    w = np.ascontiguousarray(weight, np.float64)
+    desc = _u8(desc)
+    n = len(desc)
+    wo = np.zeros(n, np.int32)
+    we = np.zeros(n, np.float64)
+    ni = np.zeros(n, np.int32)
+    lib().orc_bow_transform(_p(co), _p(ci), _p(nd), _p(wi), _p(w), depth, _p(desc), n, levelsup, _p(wo), _p(we), _p(ni))
+    return wo, we, ni

@@ -1325,4 +1325,34 @@ int orc_search_for_triangulation(const void* kps1_, const uint8_t* desc1, const 
     return nmatches;
 }
 
+
+// DBoW2::TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup)
+// (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1200-1243) on a tree given as child lists.
+// FORB::distance (FORB.cpp:90-110) is the same bit-hack popcount as DescriptorDistance.
+void orc_bow_transform(const int* child_off, const int* child_idx, const uint8_t* node_desc, const int* word_id,
+                       const double* weight, int m_L, const uint8_t* desc, int n, int levelsup, int* word_out,
+                       double* weight_out, int* nid_out) {
+    for (int f = 0; f < n; ++f) {
+        const uint8_t* feature = desc + (size_t)f * 32;
+        const int nid_level = m_L - levelsup;
+        int nid = 0;                       // root when nid_level <= 0 (the reference leaves it unset otherwise)
+        int final_id = 0, current_level = 0;
+        do {
+            ++current_level;
+            const int b = child_off[final_id], e = child_off[final_id + 1];
+            final_id = child_idx[b];
+            double best_d = hamming256(feature, node_desc + (size_t)final_id * 32);
+            for (int c = b + 1; c < e; ++c) {
+                const int id = child_idx[c];
+                const double d = hamming256(feature, node_desc + (size_t)id * 32);
+                if (d < best_d) { best_d = d; final_id = id; }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (child_off[final_id] != child_off[final_id + 1]);
+        word_out[f] = word_id[final_id];
+        weight_out[f] = weight[final_id];
+        nid_out[f] = nid;
+    }
+}
+
 }  // extern "C"

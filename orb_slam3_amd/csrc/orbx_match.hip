@@ -1451,3 +1451,171 @@ extern "C" orbx_status orbx_search_for_triangulation(const orbx_keypoint* kps1, 
     *n_matches = nm;
     return ORBX_OK;
 }
+
+// ======================================================================================
+// Bag-of-words transform: DBoW2::TemplatedVocabulary<FORB>::transform
+// (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1112-1243, called from Frame::ComputeBoW,
+// Frame.cc:872-879, with levelsup = 4).  One wave per descriptor: at every level the lanes
+// take one child each, the wave keeps the child with the smallest distance (the first among
+// equals, as the reference's strict '<' scan does) and descends until a leaf.
+// ======================================================================================
+struct orbx_vocabulary {
+    int device = 0;
+    int nNodes = 0, depth = 0;
+    int* d_childOff = nullptr;      // nNodes + 1
+    int* d_childIdx = nullptr;
+    uint32_t* d_desc = nullptr;     // nNodes x 8
+    std::vector<int> wordId;        // per node, -1 for inner nodes
+    std::vector<double> weight;     // per node
+};
+
+__global__ __launch_bounds__(256) void k_bow_descend(const int* __restrict__ childOff, const int* __restrict__ childIdx,
+                                                     const uint32_t* __restrict__ nodeDesc, const uint32_t* __restrict__ desc,
+                                                     int n, int nidLevel, int* __restrict__ leafOut, int* __restrict__ nidOut) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    uint32_t q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = desc[8ll * i + k];
+    int node = 0, level = 0, nid = 0;
+    while (true) {
+        const int b = childOff[node], e = childOff[node + 1];
+        if (b == e) break;                                    // leaf
+        ++level;
+        unsigned int key = 0xFFFFFFFFu;                       // (distance << 22) | position in the child list
+        for (int c = b + lane; c < e; c += 64) {
+            const uint32_t* d = nodeDesc + 8ll * childIdx[c];
+            int dist = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dist += __popc(q[k] ^ d[k]);
+            key = min(key, ((unsigned int)dist << 22) | (unsigned int)(c - b));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned int)__shfl_xor((int)key, off));
+        node = childIdx[b + (int)(key & 0x3FFFFFu)];
+        if (level == nidLevel) nid = node;
+    }
+    if (lane == 0) { leafOut[i] = node; nidOut[i] = nid; }
+}
+
+extern "C" orbx_status orbx_vocabulary_create(int n_nodes, const int* child_off, const int* child_idx,
+                                              const uint8_t* node_descriptors, const int* word_id, const double* weight,
+                                              int depth, int device, orbx_vocabulary** out) {
+    ORBX_REQUIRE(out && n_nodes >= 1 && child_off && node_descriptors && word_id && weight && depth >= 1, "bad argument");
+    ORBX_REQUIRE(child_off[0] == 0, "child offsets must start at 0");
+    const int nChildren = child_off[n_nodes];
+    ORBX_REQUIRE(nChildren == 0 || child_idx, "null child list");
+    for (int i = 0; i < n_nodes; ++i) {
+        ORBX_REQUIRE(child_off[i + 1] >= child_off[i] && child_off[i + 1] - child_off[i] < (1 << 22), "bad child offsets at node %d", i);
+        ORBX_REQUIRE((child_off[i + 1] == child_off[i]) == (word_id[i] >= 0), "node %d: exactly the leaves carry a word id", i);
+    }
+    // every child index in range and deeper than its parent (no cycles): a child list may only name
+    // nodes that are not ancestors; checked by a bounded breadth-first walk from the root
+    std::vector<int> levelOf(n_nodes, -1);
+    std::vector<int> frontier{0};
+    levelOf[0] = 0;
+    while (!frontier.empty()) {
+        std::vector<int> next;
+        for (int p : frontier)
+            for (int c = child_off[p]; c < child_off[p + 1]; ++c) {
+                const int ch = child_idx[c];
+                ORBX_REQUIRE(ch > 0 && ch < n_nodes, "child index %d of node %d out of range", ch, p);
+                ORBX_REQUIRE(levelOf[ch] < 0, "node %d has two parents (or the tree has a cycle)", ch);
+                levelOf[ch] = levelOf[p] + 1;
+                next.push_back(ch);
+            }
+        frontier.swap(next);
+    }
+    ORBX_HIP_TRY(hipSetDevice(device));
+    orbx_vocabulary* v = new orbx_vocabulary;
+    v->device = device; v->nNodes = n_nodes; v->depth = depth;
+    v->wordId.assign(word_id, word_id + n_nodes);
+    v->weight.assign(weight, weight + n_nodes);
+    hipError_t e = hipMalloc((void**)&v->d_childOff, (size_t)(n_nodes + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&v->d_childIdx, (size_t)std::max(nChildren, 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&v->d_desc, (size_t)n_nodes * 32);
+    if (e == hipSuccess) e = hipMemcpy(v->d_childOff, child_off, (size_t)(n_nodes + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nChildren) e = hipMemcpy(v->d_childIdx, child_idx, (size_t)nChildren * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_desc, node_descriptors, (size_t)n_nodes * 32, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        orbx_set_error("vocabulary upload failed: %s", hipGetErrorString(e));
+        hipFree(v->d_childOff); hipFree(v->d_childIdx); hipFree(v->d_desc);
+        delete v;
+        return ORBX_ERR_HIP;
+    }
+    *out = v;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_vocabulary_destroy(orbx_vocabulary* v) {
+    if (!v) return;
+    hipFree(v->d_childOff); hipFree(v->d_childIdx); hipFree(v->d_desc);
+    delete v;
+}
+
+extern "C" orbx_status orbx_bow_transform(orbx_vocabulary* voc, const uint8_t* desc, int n, int levelsup, int* word_id,
+                                          double* weight, int* node_id) {
+    ORBX_REQUIRE(voc && n >= 0 && levelsup >= 0, "bad argument");
+    if (n == 0) return ORBX_OK;
+    ORBX_REQUIRE(desc && word_id && weight && node_id, "null argument");
+    ORBX_HIP_TRY(hipSetDevice(voc->device));
+    DevBuf dd, dl, dn;
+    ORBX_HIP_TRY(dd.alloc((size_t)n * 32)); ORBX_HIP_TRY(dl.alloc((size_t)n * 4)); ORBX_HIP_TRY(dn.alloc((size_t)n * 4));
+    ORBX_HIP_TRY(hipMemcpy(dd.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    const int nidLevel = voc->depth - levelsup;     // <= 0: the feature vector node is the root
+    hipLaunchKernelGGL(k_bow_descend, dim3((n + 3) / 4), dim3(256), 0, 0, voc->d_childOff, voc->d_childIdx, voc->d_desc,
+                       dd.as<uint32_t>(), n, nidLevel, dl.as<int>(), dn.as<int>());
+    ORBX_HIP_TRY(hipGetLastError());
+    std::vector<int> leaf(n);
+    ORBX_HIP_TRY(hipMemcpy(leaf.data(), dl.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_TRY(hipMemcpy(node_id, dn.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) { word_id[i] = voc->wordId[leaf[i]]; weight[i] = voc->weight[leaf[i]]; }
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_bow_vectors(orbx_vocabulary* voc, const uint8_t* desc, int n, int levelsup, int l1_normalize,
+                                        int* bow_word, double* bow_value, int* n_bow, int* fv_node, int* fv_off,
+                                        int* fv_idx, int* n_fv_nodes) {
+    ORBX_REQUIRE(n_bow && n_fv_nodes && n >= 0, "bad argument");
+    *n_bow = 0; *n_fv_nodes = 0;
+    if (n == 0) { if (fv_off) fv_off[0] = 0; return ORBX_OK; }
+    ORBX_REQUIRE(bow_word && bow_value && fv_node && fv_off && fv_idx, "null argument");
+    std::vector<int> word(n), node(n);
+    std::vector<double> w(n);
+    orbx_status s = orbx_bow_transform(voc, desc, n, levelsup, word.data(), w.data(), node.data());
+    if (s != ORBX_OK) return s;
+    // BowVector::addWeight in feature order (TF_IDF weighting), FeatureVector::addFeature; both are
+    // std::map in the reference, i.e. ascending key order with features in insertion order
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return word[a] < word[b]; });
+    int nb = 0;
+    for (int k = 0; k < n; ++k) {
+        const int i = order[k];
+        if (!(w[i] > 0)) continue;                     // stopped word
+        if (nb > 0 && bow_word[nb - 1] == word[i]) bow_value[nb - 1] += w[i];
+        else { bow_word[nb] = word[i]; bow_value[nb] = w[i]; ++nb; }
+    }
+    if (l1_normalize) {                                // BowVector::normalize(L1)
+        double norm = 0.0;
+        for (int k = 0; k < nb; ++k) norm += std::fabs(bow_value[k]);
+        if (norm > 0.0) for (int k = 0; k < nb; ++k) bow_value[k] /= norm;
+    } else if (nb > 0) {                               // TemplatedVocabulary.h:1149-1155
+        const double nd = nb;
+        for (int k = 0; k < nb; ++k) bow_value[k] /= nd;
+    }
+    *n_bow = nb;
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return node[a] < node[b]; });
+    int nn = 0, nf = 0;
+    for (int k = 0; k < n; ++k) {
+        const int i = order[k];
+        if (!(w[i] > 0)) continue;
+        if (nn == 0 || fv_node[nn - 1] != node[i]) { fv_node[nn] = node[i]; fv_off[nn] = nf; ++nn; }
+        fv_idx[nf++] = i;
+    }
+    fv_off[nn] = nf;
+    *n_fv_nodes = nn;
+    return ORBX_OK;
+}

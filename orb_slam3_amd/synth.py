@@ -127,3 +127,51 @@ def planted_map(queries: np.ndarray, n_map: int, seed: int, max_flips: int = 40)
             d[bit >> 3] ^= np.uint8(1 << (bit & 7))
         m[r] = d
     return m, rows
+
+
+def vocabulary(k: int, depth: int, seed: int, prune: float = 0.0, shuffle_ids: bool = True):
+    """A synthetic k-ary vocabulary tree of the given depth in flattened form
+    (child_off, child_idx, node_desc, word_id, weight, depth).  Children descriptors are noisy copies of
+    their parent (so that descents are decisive high up and ambiguous near the leaves); `prune` is the
+    probability that an inner node below the root becomes a leaf early; node ids are shuffled like the
+    ids of a vocabulary file need not be consecutive per parent.  Leaf weights are positive idf-like
+    values, a few are 0 (stopped words)."""
+    rng = np.random.default_rng(seed)
+    parents, descs, levels = [-1], [rng.integers(0, 256, 32, dtype=np.uint8)], [0]
+    frontier = [0]
+    children = {0: []}
+    for lvl in range(1, depth + 1):
+        nxt = []
+        for p in frontier:
+            if lvl > 1 and rng.random() < prune:
+                continue
+            for _ in range(k):
+                d = descs[p].copy()
+                flips = rng.integers(0, 256, 24 if lvl < depth else 6)
+                for b in flips:
+                    d[b >> 3] ^= np.uint8(1 << (b & 7))
+                i = len(parents)
+                parents.append(p); descs.append(d); levels.append(lvl); children[i] = []
+                children[p].append(i)
+                nxt.append(i)
+        frontier = nxt
+    n = len(parents)
+    perm = np.arange(n)
+    if shuffle_ids:
+        perm[1:] = 1 + rng.permutation(n - 1)          # new id of old node i; the root stays 0
+    inv = np.argsort(perm)
+    child_off = np.zeros(n + 1, np.int32)
+    child_idx = []
+    for new in range(n):
+        ch = [int(perm[c]) for c in children[int(inv[new])]]
+        child_idx.extend(ch)
+        child_off[new + 1] = len(child_idx)
+    node_desc = np.stack([descs[int(inv[new])] for new in range(n)])
+    is_leaf = np.diff(child_off) == 0
+    word_id = np.full(n, -1, np.int32)
+    word_id[is_leaf] = np.arange(int(is_leaf.sum()), dtype=np.int32)
+    weight = np.zeros(n, np.float64)
+    weight[is_leaf] = rng.uniform(0.5, 9.0, int(is_leaf.sum()))
+    stopped = np.nonzero(is_leaf)[0][::37]
+    weight[stopped] = 0.0
+    return child_off, np.array(child_idx, np.int32), node_desc, word_id, weight, depth
