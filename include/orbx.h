@@ -394,6 +394,14 @@ orbx_status orbx_bow_vectors(orbx_vocabulary* voc, const uint8_t* desc, int n, i
                              int* bow_word, double* bow_value, int* n_bow,
                              int* fv_node, int* fv_off, int* fv_idx, int* n_fv_nodes);
 
+/* MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:416-533) for n_points map points at once.
+ * The observed descriptors of point p are rows off[p] .. off[p+1] of desc (at most 384 per point).
+ * best_idx[p] = the observation (relative to off[p]) with the smallest median distance to all
+ * observations of the point, the first among equal medians (-1 for a point without observations);
+ * best_median[p] = that median = element floor(0.5 * (N - 1)) of the sorted distance row. */
+orbx_status orbx_distinctive_descriptors(const uint8_t* desc, const int* off, int n_points,
+                                         int* best_idx, int* best_median);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,7 @@ def lib():
         L.orc_search_for_triangulation.restype = C.c_int
         L.orc_search_for_triangulation.argtypes = ([C.c_void_p] * 4 + [C.c_int, C.c_void_p, C.c_void_p]) * 2 + [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_bow_transform.argtypes = [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3
+        L.orc_distinctive_descriptors.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_search_by_projection.restype = C.c_int
         L.orc_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -428,3 +429,12 @@ def bow_transform(child_off, child_idx, node_desc, word_id, weight, depth, desc,
     ni = np.zeros(n, np.int32)
     lib().orc_bow_transform(_p(co), _p(ci), _p(nd), _p(wi), _p(w), depth, _p(desc), n, levelsup, _p(wo), _p(we), _p(ni))
     return wo, we, ni
+
+
+def distinctive_descriptors(desc, off):
+    desc, off = _u8(desc), _i32(off)
+    n = len(off) - 1
+    bi = np.zeros(n, np.int32)
+    bm = np.zeros(n, np.int32)
+    lib().orc_distinctive_descriptors(_p(desc), _p(off), n, _p(bi), _p(bm))
+    return bi, bm

@@ -1355,4 +1355,31 @@ void orc_bow_transform(const int* child_off, const int* child_idx, const uint8_t
     }
 }
 
+
+// MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:472-521) for one map point after another.
+void orc_distinctive_descriptors(const uint8_t* desc, const int* off, int npoints, int* best_idx, int* best_median) {
+    for (int p = 0; p < npoints; ++p) {
+        const uint8_t* D = desc + (size_t)off[p] * 32;
+        const size_t N = (size_t)(off[p + 1] - off[p]);
+        if (N == 0) { best_idx[p] = -1; best_median[p] = INT_MAX; continue; }
+        std::vector<std::vector<float>> Distances(N, std::vector<float>(N, 0.f));
+        for (size_t i = 0; i < N; i++) {
+            Distances[i][i] = 0;
+            for (size_t j = i + 1; j < N; j++) {
+                int distij = hamming256(D + i * 32, D + j * 32);
+                Distances[i][j] = (float)distij;
+                Distances[j][i] = (float)distij;
+            }
+        }
+        int BestMedian = INT_MAX, BestIdx = 0;
+        for (size_t i = 0; i < N; i++) {
+            std::vector<int> vDists(Distances[i].begin(), Distances[i].end());
+            std::sort(vDists.begin(), vDists.end());
+            int median = vDists[(size_t)(0.5 * (N - 1))];
+            if (median < BestMedian) { BestMedian = median; BestIdx = (int)i; }
+        }
+        best_idx[p] = BestIdx; best_median[p] = BestMedian;
+    }
+}
+
 }  // extern "C"

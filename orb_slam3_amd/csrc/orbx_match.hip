@@ -1619,3 +1619,78 @@ extern "C" orbx_status orbx_bow_vectors(orbx_vocabulary* voc, const uint8_t* des
     *n_fv_nodes = nn;
     return ORBX_OK;
 }
+
+// ======================================================================================
+// MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:416-533) for many map points at once:
+// per point the observation whose median Hamming distance to all observations (itself
+// included) is smallest; median = element floor(0.5 * (N - 1)) of the sorted row; the first
+// row among equal medians.  One wave per map point, one lane per row of the distance matrix.
+// ======================================================================================
+constexpr int kDistinctMaxObs = 384;
+
+__global__ __launch_bounds__(64) void k_distinctive(const uint32_t* __restrict__ desc, const int* __restrict__ off,
+                                                    int* __restrict__ bestIdx, int* __restrict__ bestMedian, int maxN) {
+    extern __shared__ __align__(16) unsigned char dd_smem[];
+    uint32_t* s_desc = reinterpret_cast<uint32_t*>(dd_smem);                       // maxN x 8
+    uint16_t* s_row = reinterpret_cast<uint16_t*>(s_desc + 8 * maxN);              // 64 rows x maxN
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int b = off[p], N = off[p + 1] - b;
+    if (N <= 0) { if (lane == 0) { bestIdx[p] = -1; bestMedian[p] = INT_MAX; } return; }
+    for (int i = lane; i < 8 * N; i += 64) s_desc[i] = desc[8ll * b + i];
+    __syncthreads();
+    const int kth = (int)(0.5 * (N - 1));            // vDists[0.5 * (N - 1)]
+    unsigned int best = 0xFFFFFFFFu;                 // (median << 16) | row
+    uint16_t* row = s_row + lane * maxN;
+    for (int i = lane; i < N; i += 64) {
+        uint32_t q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) q[k] = s_desc[8 * i + k];
+        for (int j = 0; j < N; ++j) {
+            int d = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d += __popc(q[k] ^ s_desc[8 * j + k]);
+            row[j] = (uint16_t)d;
+        }
+        // smallest v with #{j : row[j] <= v} > kth  (the kth element of the sorted row)
+        int lo = 0, hi = 256;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            int cnt = 0;
+            for (int j = 0; j < N; ++j) cnt += (row[j] <= mid) ? 1 : 0;
+            if (cnt > kth) hi = mid; else lo = mid + 1;
+        }
+        best = min(best, ((unsigned int)lo << 16) | (unsigned int)i);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned int)__shfl_xor((int)best, o));
+    if (lane == 0) { bestIdx[p] = (int)(best & 0xFFFFu); bestMedian[p] = (int)(best >> 16); }
+}
+
+extern "C" orbx_status orbx_distinctive_descriptors(const uint8_t* desc, const int* off, int n_points, int* best_idx,
+                                                    int* best_median) {
+    ORBX_REQUIRE(n_points >= 0, "negative size");
+    if (n_points == 0) return ORBX_OK;
+    ORBX_REQUIRE(off && best_idx && best_median && off[0] == 0, "bad argument");
+    int maxN = 1;
+    for (int p = 0; p < n_points; ++p) {
+        ORBX_REQUIRE(off[p + 1] >= off[p], "bad offsets");
+        ORBX_REQUIRE(off[p + 1] - off[p] <= kDistinctMaxObs, "map point %d has %d observations, at most %d are supported", p,
+                     off[p + 1] - off[p], kDistinctMaxObs);
+        maxN = std::max(maxN, off[p + 1] - off[p]);
+    }
+    const int total = off[n_points];
+    ORBX_REQUIRE(total == 0 || desc, "null descriptors");
+    DevBuf dD, dO, dI, dM;
+    ORBX_HIP_TRY(dD.alloc((size_t)std::max(total, 1) * 32)); ORBX_HIP_TRY(dO.alloc((size_t)(n_points + 1) * 4));
+    ORBX_HIP_TRY(dI.alloc((size_t)n_points * 4)); ORBX_HIP_TRY(dM.alloc((size_t)n_points * 4));
+    if (total) ORBX_HIP_TRY(hipMemcpy(dD.p, desc, (size_t)total * 32, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(hipMemcpy(dO.p, off, (size_t)(n_points + 1) * 4, hipMemcpyHostToDevice));
+    maxN = (maxN + 1) & ~1;
+    const size_t lds = (size_t)maxN * 32 + (size_t)64 * maxN * 2;      // <= 61440 bytes at 384 observations
+    hipLaunchKernelGGL(k_distinctive, dim3(n_points), dim3(64), lds, 0, dD.as<uint32_t>(), dO.as<int>(), dI.as<int>(),
+                       dM.as<int>(), maxN);
+    ORBX_HIP_TRY(hipGetLastError());
+    ORBX_HIP_TRY(hipMemcpy(best_idx, dI.p, (size_t)n_points * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_TRY(hipMemcpy(best_median, dM.p, (size_t)n_points * 4, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}

@@ -317,3 +317,15 @@ def bucket_best(desc1, idx1, off1, desc2, idx2, off2):
     check(lib().orbx_bucket_best(ptr(desc1), len(desc1), ptr(idx1), ptr(off1), ptr(desc2), len(desc2), ptr(idx2),
                                  ptr(off2), len(off1) - 1, ptr(bi), ptr(bd)))
     return bi, bd
+
+
+def distinctive_descriptors(desc, off):
+    """MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:416-533) batched over map points: desc [total, 32],
+    off [n_points + 1]; returns (best observation per point relative to its first row, its median distance)."""
+    desc = _desc(desc) if len(desc) else np.zeros((0, 32), np.uint8)
+    off = np.ascontiguousarray(off, np.int32)
+    n = len(off) - 1
+    bi = np.full(n, -1, np.int32)
+    bm = np.zeros(n, np.int32)
+    check(lib().orbx_distinctive_descriptors(ptr(desc), ptr(off), n, ptr(bi), ptr(bm)))
+    return bi, bm

@@ -84,3 +84,22 @@ def test_bow_feeds_the_bow_matcher(oracle):
     assert n == n_o and np.array_equal(m12, m12_o)
     good = m12 >= 0
     assert good.sum() > 300 and (perm[m12[good]] == np.nonzero(good)[0]).mean() > 0.9
+
+
+def test_distinctive_descriptors(oracle):
+    """MapPoint::ComputeDistinctiveDescriptors batched: observation counts 0 .. 384, ties between medians."""
+    A = _gpu()
+    rng = np.random.default_rng(21)
+    counts = [0, 1, 2, 3, 4, 5, 7, 8, 15, 16, 31, 63, 64, 65, 100, 129, 384] + list(rng.integers(2, 30, 400))
+    off = np.zeros(len(counts) + 1, np.int32)
+    off[1:] = np.cumsum(counts)
+    base = synth.random_descriptors(len(counts), 22)
+    desc = np.repeat(base, counts, axis=0)
+    for i in range(len(desc)):
+        for b in rng.integers(0, 256, int(rng.integers(0, 30))):
+            desc[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    desc[off[10]:off[10] + 8] = desc[off[10]]          # identical observations: all medians tie, the first row wins
+    bi_o, bm_o = oracle.distinctive_descriptors(desc, off)
+    bi, bm = A.distinctive_descriptors(desc, off)
+    assert np.array_equal(bi, bi_o) and np.array_equal(bm, bm_o)
+    assert bi[0] == -1 and bi[1] == 0 and bm[1] == 0

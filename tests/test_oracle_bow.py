@@ -35,3 +35,28 @@ def test_first_minimum_wins(oracle):
     w = np.array([0, 1.0, 2.0, 3.0])
     wo, we, ni = oracle.bow_transform(child_off, child_idx, nd, word, w, 1, np.zeros((1, 32), np.uint8), 0)
     assert list(wo) == [2] and list(ni) == [3]
+
+
+def test_distinctive_descriptor_by_hand(oracle):
+    # three observations with 0, 4 and 8 bits set: rows of the distance matrix [0 4 8], [4 0 4], [8 4 0];
+    # medians (element 1 of the sorted row) 4, 4, 4 -> all tie, row 0 wins; with a fourth far one the middle wins
+    d = np.zeros((3, 32), np.uint8)
+    d[1, 0] = 0x0F
+    d[2, 0] = 0xFF
+    bi, bm = oracle.distinctive_descriptors(d, np.array([0, 3], np.int32))
+    assert list(bi) == [0] and list(bm) == [4]
+    d4 = np.zeros((4, 32), np.uint8)
+    d4[1, 0] = 0x0F
+    d4[2, 0] = 0xFF
+    d4[3, :4] = 0xFF                   # 32 bits
+    # rows sorted: [0 4 8 32], [0 4 4 28], [0 4 8 24], [0 24 28 32]; element floor(0.5 * 3) = 1 -> 4, 4, 4, 24
+    bi, bm = oracle.distinctive_descriptors(d4, np.array([0, 4], np.int32))
+    assert list(bi) == [0] and list(bm) == [4]
+    # five observations: element 2 of the sorted rows
+    d5 = np.zeros((5, 32), np.uint8)
+    for i, nb in enumerate([0, 2, 4, 6, 30]):
+        for b in range(nb):
+            d5[i, b >> 3] |= np.uint8(1 << (b & 7))
+    # distances |a - b| in set bits: rows 1 and 2 both have the sorted row [0 2 2 4 x] -> median 2; row 1 comes first
+    bi, bm = oracle.distinctive_descriptors(d5, np.array([0, 5], np.int32))
+    assert list(bi) == [1] and list(bm) == [2]
