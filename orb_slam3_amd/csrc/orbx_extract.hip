@@ -73,16 +73,20 @@ struct OrbxErr {
 
 // ======================================================================================
 // k_resize: 8-bit bilinear resize in 11-bit fixed point, 4 output pixels per lane.
-// The source bytes a lane needs (two rows, <= 16 consecutive columns for scale factors up to
-// 3) are fetched as aligned dwords and picked apart in registers; the per-column taps come
+// The 8 source bytes that the lane's 4 outputs touch in one source row (scale factors up to 2) are
+// cut out of three aligned dwords; one v_perm_b32 per tap gathers the four left / the four right
+// neighbours, so a source row costs two permutes instead of eight byte extractions.  The taps come
 // as one int4 of source offsets and one uint4 of packed (a0 | a1 << 16) coefficients.
 // ======================================================================================
-__device__ __forceinline__ int pick_byte(unsigned long long lo, unsigned long long hi, int k) {
-    const unsigned long long v = (k < 8) ? lo : hi;
-    return (int)((v >> ((k & 7) * 8)) & 255ull);
-}
-
 constexpr int kResizeRows = 4;   // output rows per lane: taps are fetched once, source rows are reused
+
+// the four left (.x) and right (.y) neighbours of a lane's outputs in source row `row`
+__device__ __forceinline__ uint2 resize_gather(const uint8_t* __restrict__ row, int base, int sh, uint32_t sel0, uint32_t sel1) {
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(row + base);
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return make_uint2(__builtin_amdgcn_perm(w1, w0, sel0), __builtin_amdgcn_perm(w1, w0, sel1));
+}
 
 __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__ geo, int level,
                                                 uint8_t* __restrict__ pyr, long long frameStride,
@@ -100,17 +104,24 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__
     const uint4 c = *reinterpret_cast<const uint4*>(xcoef + D.tapX + x4);
     const int so[4] = {o.x, o.y, o.z, o.w};
     const uint32_t co[4] = {c.x, c.y, c.z, c.w};
-    const int last = min(o.w + 1, S.w - 1);
-    const int base = o.x & ~3;
-    const bool window = last - base < 16;
-    int k0[4], k1[4];
+    int a0[4], a1[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { k0[i] = so[i] - base; k1[i] = min(so[i] + 1, S.w - 1) - base; }
+    for (int i = 0; i < 4; ++i) { a0[i] = (int)(co[i] & 0xFFFFu); a1[i] = (int)(co[i] >> 16); }
+    // byte positions inside the 8-byte window that starts at source column so[0]
+    const int last = min(o.w + 1, S.w - 1);
+    const bool window = last - o.x < 8;
+    uint32_t sel0 = 0, sel1 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        sel0 |= (uint32_t)((so[i] - o.x) & 7) << (8 * i);
+        sel1 |= (uint32_t)((min(so[i] + 1, S.w - 1) - o.x) & 7) << (8 * i);
+    }
+    const int base = o.x & ~3, sh = o.x & 3;
 
-    // the 16-byte window of the previous lower source row is kept: consecutive output rows
+    // the gathered bytes of the previous lower source row are kept: consecutive output rows
     // usually continue from it (sy0 of this row == sy1 of the previous one)
     int heldRow = -1;
-    unsigned long long heldLo = 0, heldHi = 0;
+    uint2 held = make_uint2(0u, 0u);
     for (int r = 0; r < kResizeRows; ++r) {
         const int y = yFirst + r;
         if (y >= D.h) break;
@@ -122,23 +133,13 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__
         const uint8_t* r1 = src + (long long)sy1 * S.pitch;
         uint32_t packed = 0;
         if (window) {
-            unsigned long long lo0, hi0, lo1, hi1;
-            if (sy0 == heldRow) { lo0 = heldLo; hi0 = heldHi; }
-            else {
-                const uint32_t* p0 = reinterpret_cast<const uint32_t*>(r0 + base);
-                lo0 = p0[0] | ((unsigned long long)p0[1] << 32); hi0 = p0[2] | ((unsigned long long)p0[3] << 32);
-            }
-            if (sy1 == sy0) { lo1 = lo0; hi1 = hi0; }
-            else {
-                const uint32_t* p1 = reinterpret_cast<const uint32_t*>(r1 + base);
-                lo1 = p1[0] | ((unsigned long long)p1[1] << 32); hi1 = p1[2] | ((unsigned long long)p1[3] << 32);
-            }
-            heldRow = sy1; heldLo = lo1; heldHi = hi1;
+            const uint2 g0 = (sy0 == heldRow) ? held : resize_gather(r0, base, sh, sel0, sel1);
+            const uint2 g1 = (sy1 == sy0) ? g0 : resize_gather(r1, base, sh, sel0, sel1);
+            heldRow = sy1; held = g1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int a0 = (int)(co[i] & 0xFFFFu), a1 = (int)(co[i] >> 16);
-                const int t0 = pick_byte(lo0, hi0, k0[i]) * a0 + pick_byte(lo0, hi0, k1[i]) * a1;
-                const int t1 = pick_byte(lo1, hi1, k0[i]) * a0 + pick_byte(lo1, hi1, k1[i]) * a1;
+                const int t0 = (int)((g0.x >> (8 * i)) & 255u) * a0[i] + (int)((g0.y >> (8 * i)) & 255u) * a1[i];
+                const int t1 = (int)((g1.x >> (8 * i)) & 255u) * a0[i] + (int)((g1.y >> (8 * i)) & 255u) * a1[i];
                 const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
                 packed |= (uint32_t)(v & 255) << (8 * i);
             }
@@ -146,9 +147,8 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int sx0 = so[i], sx1 = min(sx0 + 1, S.w - 1);
-                const int a0 = (int)(co[i] & 0xFFFFu), a1 = (int)(co[i] >> 16);
-                const int t0 = r0[sx0] * a0 + r0[sx1] * a1;
-                const int t1 = r1[sx0] * a0 + r1[sx1] * a1;
+                const int t0 = r0[sx0] * a0[i] + r0[sx1] * a1[i];
+                const int t1 = r1[sx0] * a0[i] + r1[sx1] * a1[i];
                 const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
                 packed |= (uint32_t)(v & 255) << (8 * i);
             }
