@@ -955,10 +955,18 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     const int ox = interior ? px0 - xa : 0;
     if (active) {
         if (interior) {
-            for (int i = lane; i < kRawW * (kRawP / 16); i += 64) {
-                const int r = i >> 2, d = i & 3;
-                *reinterpret_cast<uint4*>(rawBase + r * kRawP + 16 * d) =
-                    *reinterpret_cast<const uint4*>(img + (long long)(py0 + r) * G.pitch + xa + 16 * d);
+            // 43 rows x 4 chunks of 16 bytes = 172 loads: three per lane, issued together
+            uint4 v[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = lane + 64 * u, r = i >> 2, d = i & 3;
+                if (i < kRawW * (kRawP / 16))
+                    v[u] = *reinterpret_cast<const uint4*>(img + (long long)(py0 + r) * G.pitch + xa + 16 * d);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int i = lane + 64 * u, r = i >> 2, d = i & 3;
+                if (i < kRawW * (kRawP / 16)) *reinterpret_cast<uint4*>(rawBase + r * kRawP + 16 * d) = v[u];
             }
         } else {
             for (int i = lane; i < kRawW * kRawW; i += 64) {
