@@ -196,13 +196,17 @@ __device__ __forceinline__ us2 pk_swap(us2 a) { return __builtin_shufflevector(a
 // holds (p[k], p[k+8]), so one packed op advances arcs k and k+8 together; the second half of
 // the cyclic sequence is the same registers with their halves swapped.
 __device__ __forceinline__ int fast_strength_lds(const uint8_t* t, int P, int x, int y) {
-    const uint8_t* c = t + y * P + x;
-    const int v = c[0];
+    // addressed from the top-left corner of the 7x7 neighbourhood: every offset is non-negative
+    // (an immediate when the pitch is a compile-time constant)
+    const uint8_t* c = t + (y - 3) * P + (x - 3);
+#define ORBX_PX(dx, dy) c[(3 + (dy)) * P + 3 + (dx)]
+    const int v = ORBX_PX(0, 0);
     us2 E[16];
-    E[0] = us2{c[3 * P], c[-3 * P]};           E[1] = us2{c[3 * P + 1], c[-3 * P - 1]};
-    E[2] = us2{c[2 * P + 2], c[-2 * P - 2]};   E[3] = us2{c[P + 3], c[-P - 3]};
-    E[4] = us2{c[3], c[-3]};                   E[5] = us2{c[-P + 3], c[P - 3]};
-    E[6] = us2{c[-2 * P + 2], c[2 * P - 2]};   E[7] = us2{c[-3 * P + 1], c[3 * P - 1]};
+    E[0] = us2{ORBX_PX(0, 3), ORBX_PX(0, -3)};     E[1] = us2{ORBX_PX(1, 3), ORBX_PX(-1, -3)};
+    E[2] = us2{ORBX_PX(2, 2), ORBX_PX(-2, -2)};    E[3] = us2{ORBX_PX(3, 1), ORBX_PX(-3, -1)};
+    E[4] = us2{ORBX_PX(3, 0), ORBX_PX(-3, 0)};     E[5] = us2{ORBX_PX(3, -1), ORBX_PX(-3, 1)};
+    E[6] = us2{ORBX_PX(2, -2), ORBX_PX(-2, 2)};    E[7] = us2{ORBX_PX(1, -3), ORBX_PX(-1, 3)};
+#undef ORBX_PX
 #pragma unroll
     for (int k = 0; k < 8; ++k) E[8 + k] = pk_swap(E[k]);
     us2 hi2[10], lo2[10], hi4[12], lo4[12];
@@ -373,14 +377,14 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     for (int q = tid; q < nQueue; q += kFastThreads) {
         const int rec = s_queue[q];
         const int x = rec & 127, y = rec >> 7;
-        const int st = S[y * P + x];
+        const uint8_t* sp = S + (y - 1) * P + (x - 1);   // top-left of the 3x3 neighbourhood
+        const int st = sp[P + 1];
         int flags = 0;
         if (st != 0) {
             int nb[8];
-            nb[0] = S[(y - 1) * P + x - 1]; nb[1] = S[(y - 1) * P + x];
-            nb[2] = S[(y - 1) * P + x + 1]; nb[3] = S[y * P + x - 1];
-            nb[4] = S[y * P + x + 1];       nb[5] = S[(y + 1) * P + x - 1];
-            nb[6] = S[(y + 1) * P + x];     nb[7] = S[(y + 1) * P + x + 1];
+            nb[0] = sp[0];         nb[1] = sp[1];         nb[2] = sp[2];
+            nb[3] = sp[P];                                nb[4] = sp[P + 2];
+            nb[5] = sp[2 * P];     nb[6] = sp[2 * P + 1]; nb[7] = sp[2 * P + 2];
             const int sI = score_at(st, iniTh), sM = score_at(st, minTh);
             bool keepI = st > iniTh, keepM = st > minTh;
 #pragma unroll
