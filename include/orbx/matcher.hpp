@@ -41,8 +41,115 @@ public:
         return n;
     }
 
+    // A frame / keyframe side of a windowed search: undistorted keypoints, descriptors, optional right
+    // coordinates and the image bounds of its grid (mnMinX, mnMaxX, mnMinY, mnMaxY).
+    struct View {
+        const std::vector<orbx_keypoint>* keys;
+        const std::vector<uint8_t>* descriptors;
+        const float* uRight;
+        float bounds[4];
+        int size() const { return (int)keys->size(); }
+    };
+
+    // Best-only loop shared by SearchByProjection(Frame&, const Frame&, ...) (ORBmatcher.cc:1761),
+    // (Frame&, KeyFrame*, sFound, th, ORBdist) (:1974), (KeyFrame*, Sim3, points, matched, th, ratio) (:476, :582)
+    // and Fuse(KeyFrame*, Sim3, ...) (:1409).  kpMatch[i] = query that owns keypoint i afterwards (-1 none);
+    // queryAngles is used only when this matcher checks orientation.  Returns the reference's return value.
+    int SearchWindowBest(const View& v, const std::vector<orbx_query>& queries, const std::vector<uint8_t>& queryDescriptors,
+                         float maxDist, std::vector<uint8_t>* taken, const uint8_t* queryMarks, const float* queryAngles,
+                         std::vector<int>& matchOut, std::vector<int>& kpMatch, float rotFactor = 1.0f / HISTO_LENGTH) const {
+        int n = 0;
+        matchOut.assign(queries.size(), -1);
+        kpMatch.assign(v.keys->size(), -1);
+        check(orbx_search_window_best(v.keys->data(), v.descriptors->data(), v.uRight, v.size(), v.bounds[0], v.bounds[1],
+                                      v.bounds[2], v.bounds[3], queries.data(), queryDescriptors.data(), (int)queries.size(),
+                                      maxDist, taken ? taken->data() : nullptr, queryMarks,
+                                      mbCheckOrientation ? queryAngles : nullptr, rotFactor, matchOut.data(), kpMatch.data(), &n));
+        return n;
+    }
+
+    // Matching part of Fuse(KeyFrame*, const vector<MapPoint*>&, th, bRight) (ORBmatcher.cc:1214-1407).
+    int Fuse(const View& v, const std::vector<orbx_query>& queries, const std::vector<uint8_t>& queryDescriptors,
+             const std::vector<float>& invLevelSigma2, std::vector<int>& matchOut) const {
+        int n = 0;
+        matchOut.assign(queries.size(), -1);
+        check(orbx_fuse_search(v.keys->data(), v.descriptors->data(), v.uRight, v.size(), v.bounds[0], v.bounds[1], v.bounds[2],
+                               v.bounds[3], queries.data(), queryDescriptors.data(), (int)queries.size(), invLevelSigma2.data(),
+                               (int)invLevelSigma2.size(), matchOut.data(), &n));
+        return n;
+    }
+
+    // SearchForInitialization (ORBmatcher.cc:695-808).  vbPrevMatched holds {x, y} pairs and is updated.
+    int SearchForInitialization(const View& f1, const View& f2, std::vector<float>& vbPrevMatched,
+                                std::vector<int>& vnMatches12, int windowSize = 10) const {
+        int n = 0;
+        vnMatches12.assign(f1.keys->size(), -1);
+        check(orbx_search_for_initialization(f1.keys->data(), f1.descriptors->data(), f1.size(), f2.keys->data(),
+                                             f2.descriptors->data(), f2.size(), f2.bounds[0], f2.bounds[1], f2.bounds[2],
+                                             f2.bounds[3], vbPrevMatched.data(), windowSize, mfNNratio,
+                                             mbCheckOrientation ? 1 : 0, vnMatches12.data(), &n));
+        return n;
+    }
+
+    // A DBoW2::FeatureVector restricted to the nodes two vectors share, as CSR (idx[off[b] .. off[b+1]) = node b).
+    struct NodeLists {
+        std::vector<int> idx, off;
+        int nodes() const { return off.empty() ? 0 : (int)off.size() - 1; }
+    };
+
+    // SearchByBoW(KeyFrame*, KeyFrame*, matches12) (ORBmatcher.cc:824-966).
+    int SearchByBoW(const std::vector<uint8_t>& desc1, const std::vector<float>& angle1, const std::vector<uint8_t>& valid1,
+                    const NodeLists& fv1, const std::vector<uint8_t>& desc2, const std::vector<float>& angle2,
+                    const std::vector<uint8_t>& valid2, const NodeLists& fv2, std::vector<int>& matches12) const {
+        int n = 0;
+        matches12.assign(valid1.size(), -1);
+        check(orbx_search_by_bow_keyframes(desc1.data(), angle1.data(), valid1.data(), (int)valid1.size(), fv1.idx.data(),
+                                           fv1.off.data(), desc2.data(), angle2.data(), valid2.data(), (int)valid2.size(),
+                                           fv2.idx.data(), fv2.off.data(), fv1.nodes(), mfNNratio, mbCheckOrientation ? 1 : 0,
+                                           matches12.data(), &n));
+        return n;
+    }
+
+    // SearchByBoW(KeyFrame*, Frame&, matches) (ORBmatcher.cc:235-474): matchF[i] = keyframe keypoint or -1.
+    int SearchByBoW(const std::vector<uint8_t>& descKF, const std::vector<float>& angleKF, const std::vector<uint8_t>& validKF,
+                    const NodeLists& fvKF, const std::vector<uint8_t>& descF, const std::vector<float>& angleF, int nLeftF,
+                    const NodeLists& fvF, std::vector<int>& matchF) const {
+        int n = 0;
+        matchF.assign(angleF.size(), -1);
+        check(orbx_search_by_bow(descKF.data(), angleKF.data(), validKF.data(), (int)validKF.size(), fvKF.idx.data(),
+                                 fvKF.off.data(), descF.data(), angleF.data(), (int)angleF.size(), nLeftF, fvF.idx.data(),
+                                 fvF.off.data(), fvKF.nodes(), mfNNratio, mbCheckOrientation ? 1 : 0, matchF.data(), &n));
+        return n;
+    }
+
     float mfNNratio;
     bool mbCheckOrientation;
+};
+
+// ORBVocabulary::transform as called by Frame::ComputeBoW (Frame.cc:872-879): BowVector as ascending
+// (word, value) pairs, FeatureVector as CSR over ascending node ids.
+class Vocabulary {
+public:
+    Vocabulary(int nNodes, const int* childOff, const int* childIdx, const uint8_t* nodeDescriptors, const int* wordId,
+               const double* weight, int depth, int device = 0) {
+        check(orbx_vocabulary_create(nNodes, childOff, childIdx, nodeDescriptors, wordId, weight, depth, device, &h_));
+    }
+    ~Vocabulary() { orbx_vocabulary_destroy(h_); }
+    Vocabulary(const Vocabulary&) = delete;
+    Vocabulary& operator=(const Vocabulary&) = delete;
+
+    void transform(const uint8_t* descriptors, int n, std::vector<int>& bowWord, std::vector<double>& bowValue,
+                   std::vector<int>& fvNode, std::vector<int>& fvOff, std::vector<int>& fvIdx, int levelsup = 4) const {
+        bowWord.assign(n, 0); bowValue.assign(n, 0.0); fvNode.assign(n, 0); fvOff.assign(n + 1, 0); fvIdx.assign(n, 0);
+        int nb = 0, nn = 0;
+        check(orbx_bow_vectors(h_, descriptors, n, levelsup, 1, bowWord.data(), bowValue.data(), &nb, fvNode.data(),
+                               fvOff.data(), fvIdx.data(), &nn));
+        bowWord.resize(nb); bowValue.resize(nb); fvNode.resize(nn); fvOff.resize(nn + 1); fvIdx.resize(fvOff[nn]);
+    }
+    orbx_vocabulary* handle() const { return h_; }
+
+private:
+    orbx_vocabulary* h_ = nullptr;
 };
 
 // Frame::ComputeStereoMatches (Frame.cc:962-1133): fills mvuRight / mvDepth.

@@ -39,12 +39,20 @@ int main(int argc, char** argv) {
         const float mbf = 47.90639384423901f, fx = 435.2046959714599f;
         orbx::ComputeStereoMatches(exL, exR, kL, dL, kR, dR, mbf, mbf / fx, uR, depth);
         std::vector<orbx_match2> knn = orbx::KnnMatch2(dL.data(), (int)kL.size(), dR.data(), (int64_t)kR.size());
+        // SearchForInitialization between the two images (as ORBmatcher(0.9, true) with a 100 px window)
+        orbx::Matcher matcher(0.9f, true);
+        orbx::Matcher::View v1{&kL, &dL, nullptr, {0.f, (float)W, 0.f, (float)H}}, v2{&kR, &dR, nullptr, {0.f, (float)W, 0.f, (float)H}};
+        std::vector<float> prev(2 * kL.size());
+        for (size_t i = 0; i < kL.size(); ++i) { prev[2 * i] = kL[i].x; prev[2 * i + 1] = kL[i].y; }
+        std::vector<int> m12;
+        const int nInit = matcher.SearchForInitialization(v1, v2, prev, m12, 100);
         std::string pre = argv[5];
+        dump(pre + "_m12.bin", m12); dump(pre + "_prev.bin", prev);
         dump(pre + "_kL.bin", kL); dump(pre + "_dL.bin", dL); dump(pre + "_kR.bin", kR); dump(pre + "_dR.bin", dR);
         dump(pre + "_uR.bin", uR); dump(pre + "_depth.bin", depth); dump(pre + "_knn.bin", knn);
         dump(pre + "_pyr3.bin", exL.mvImagePyramid.at(3).pixels);
-        std::printf("monoL=%d monoR=%d monoEmpty=%d nL=%zu nR=%zu levels=%d sf1=%.9g\n", monoL, monoR, monoEmpty, kL.size(),
-                    kR.size(), exL.GetLevels(), exL.GetScaleFactors().at(1));
+        std::printf("monoL=%d monoR=%d monoEmpty=%d nL=%zu nR=%zu levels=%d sf1=%.9g nInit=%d\n", monoL, monoR, monoEmpty,
+                    kL.size(), kR.size(), exL.GetLevels(), exL.GetScaleFactors().at(1), nInit);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

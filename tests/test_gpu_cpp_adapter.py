@@ -43,3 +43,10 @@ def test_cpp_adapter_matches_oracle(oracle, tmp_path):
     ref = oracle.knn2(dL, dR)
     assert np.array_equal(np.stack([knn["idx0"], knn["dist0"], knn["idx1"], knn["dist1"]], 1), ref)
     assert np.array_equal(rd("_pyr3.bin", np.uint8), pl[3].ravel())
+    # orbx::Matcher::SearchForInitialization through the C++ layer
+    g2 = oracle.Grid(kR, 0.0, 752.0, 0.0, 480.0)
+    prev = np.stack([kL["x"], kL["y"]], 1).astype(np.float32)
+    m12, prev2, n = oracle.search_for_initialization(kL, dL, g2, dR, prev, 100, 0.9, True)
+    assert f"nInit={n}" in out.stdout and n > 10
+    assert np.array_equal(rd("_m12.bin", np.int32), m12)
+    assert np.array_equal(rd("_prev.bin", np.float32).reshape(-1, 2), prev2)
