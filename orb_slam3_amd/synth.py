@@ -175,3 +175,93 @@ def vocabulary(k: int, depth: int, seed: int, prune: float = 0.0, shuffle_ids: b
     stopped = np.nonzero(is_leaf)[0][::37]
     weight[stopped] = 0.0
     return child_off, np.array(child_idx, np.int32), node_desc, word_id, weight, depth
+
+
+# ---- inputs for the matcher tests (frames of keypoints with descriptors that are noisy copies of a
+# ---- small base set, so that distances straddle the thresholds and ties occur) ----------------------
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+QUERY_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("xr", "<f4"), ("radius", "<f4"),
+                        ("min_level", "<i4"), ("max_level", "<i4")])
+SCALE_FACTORS = np.array([1.2 ** i for i in range(8)], np.float32)
+
+
+def noisy_copy(rng, desc, max_flips):
+    out = desc.copy()
+    for i in range(len(out)):
+        for b in rng.integers(0, 256, int(rng.integers(0, max_flips))):
+            out[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    return out
+
+
+def matcher_frame(rng, n, base_desc=None, flips=30):
+    """Random keypoints in a 752x480 image with descriptors that are noisy copies of base_desc rows."""
+    kps = np.zeros(n, KP_DTYPE)
+    kps["x"] = rng.uniform(5, 747, n).astype(np.float32)
+    kps["y"] = rng.uniform(5, 475, n).astype(np.float32)
+    kps["octave"] = rng.integers(0, 8, n)
+    kps["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+    kps["size"] = 31
+    if base_desc is None:
+        desc = random_descriptors(n, int(rng.integers(1 << 30)))
+    else:
+        desc = noisy_copy(rng, base_desc[rng.integers(0, len(base_desc), n)], flips)
+    return kps, desc
+
+
+def projected_queries(rng, kps, n, th=7.0, jitter=6.0):
+    """Queries projected near existing keypoints: (queries, predicted level, source keypoint)."""
+    src = rng.integers(0, len(kps), n)
+    q = np.zeros(n, QUERY_DTYPE)
+    q["x"] = kps["x"][src] + rng.normal(0, jitter, n).astype(np.float32)
+    q["y"] = kps["y"][src] + rng.normal(0, jitter, n).astype(np.float32)
+    lvl = np.clip(kps["octave"][src] + rng.integers(-1, 2, n), 0, 7).astype(np.int32)
+    q["radius"] = (th * SCALE_FACTORS[lvl]).astype(np.float32)
+    q["min_level"] = lvl - 1
+    q["max_level"] = lvl
+    return q, lvl, src
+
+
+def feature_vector(rng, n, n_nodes):
+    """Random assignment of n features to n_nodes vocabulary nodes as CSR (idx, off), features ascending."""
+    node = rng.integers(0, n_nodes, n)
+    order = np.argsort(node, kind="stable")
+    off = np.zeros(n_nodes + 1, np.int32)
+    np.add.at(off, node + 1, 1)
+    return order.astype(np.int32), np.cumsum(off).astype(np.int32)
+
+
+def matcher_golden_cases():
+    """The seeded inputs of the committed matcher golden vectors (tests/golden/matchers.npz): a dict of
+    name -> dict of arrays.  Shared by tools/make_golden.py and the tests that replay them."""
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    cases = {}
+    rng = np.random.default_rng(101)
+    base = random_descriptors(300, 102)
+    kps, desc = matcher_frame(rng, 1200, base)
+    ur = np.where(rng.random(len(kps)) < 0.6, kps["x"] - rng.uniform(1, 40, len(kps)), -1).astype(np.float32)
+    q, lvl, src = projected_queries(rng, kps, 700)
+    q["xr"] = q["x"] - rng.uniform(1, 40, len(q)).astype(np.float32)
+    cases["window"] = dict(kps=kps, desc=desc, ur=ur, q=q, lvl=lvl, qdesc=noisy_copy(rng, desc[src], 60),
+                           qangle=((kps["angle"][src] + rng.normal(40, 25, len(q))) % 360).astype(np.float32),
+                           taken=(rng.random(len(kps)) < 0.2).astype(np.uint8),
+                           marks=(rng.random(len(q)) < 0.8).astype(np.uint8), bounds=np.array(bounds, np.float32))
+    rng = np.random.default_rng(103)
+    base = random_descriptors(120, 104)
+    k1, d1 = matcher_frame(rng, 800, base, 16)
+    k2, d2 = matcher_frame(rng, 850, base, 16)
+    fv1, fv2 = feature_vector(rng, 800, 30), feature_vector(rng, 850, 30)
+    cases["bow"] = dict(d1=d1, a1=k1["angle"], v1=(rng.random(800) < 0.7).astype(np.uint8), i1=fv1[0], o1=fv1[1],
+                        d2=d2, a2=k2["angle"], v2=(rng.random(850) < 0.7).astype(np.uint8), i2=fv2[0], o2=fv2[1])
+    voc = vocabulary(10, 3, 105)
+    rng = np.random.default_rng(106)
+    leaves = np.nonzero(voc[3] >= 0)[0]
+    feat = noisy_copy(rng, voc[2][rng.choice(leaves, 600)], 40)
+    cases["vocabulary"] = dict(child_off=voc[0], child_idx=voc[1], node_desc=voc[2], word_id=voc[3], weight=voc[4],
+                               depth=np.int32(voc[5]), features=feat)
+    counts = rng.integers(1, 25, 120)
+    off = np.zeros(len(counts) + 1, np.int32)
+    off[1:] = np.cumsum(counts)
+    obs = noisy_copy(rng, np.repeat(random_descriptors(len(counts), 107), counts, axis=0), 30)
+    cases["distinctive"] = dict(desc=obs, off=off)
+    return cases

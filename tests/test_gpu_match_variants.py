@@ -19,46 +19,15 @@ def _gpu():
 
 
 def _frame(rng, n, A, base_desc=None, flips=30):
-    """Random keypoints (clustered so windows hold many candidates) with descriptors that are noisy
-    copies of base_desc rows (so distances straddle the thresholds and ties occur)."""
-    kps = np.zeros(n, A.KP_DTYPE)
-    kps["x"] = rng.uniform(5, 747, n).astype(np.float32)
-    kps["y"] = rng.uniform(5, 475, n).astype(np.float32)
-    kps["octave"] = rng.integers(0, 8, n)
-    kps["angle"] = rng.uniform(0, 360, n).astype(np.float32)
-    kps["size"] = 31
-    if base_desc is None:
-        desc = synth.random_descriptors(n, int(rng.integers(1 << 30)))
-    else:
-        src = rng.integers(0, len(base_desc), n)
-        desc = base_desc[src].copy()
-        for i in range(n):
-            k = int(rng.integers(0, flips))
-            bits = rng.integers(0, 256, k)
-            for b in bits:
-                desc[i, b >> 3] ^= np.uint8(1 << (b & 7))
-    return kps, desc
+    return synth.matcher_frame(rng, n, base_desc, flips)
 
 
 def _noisy(rng, desc, max_flips):
-    out = desc.copy()
-    for i in range(len(out)):
-        for b in rng.integers(0, 256, int(rng.integers(0, max_flips))):
-            out[i, b >> 3] ^= np.uint8(1 << (b & 7))
-    return out
+    return synth.noisy_copy(rng, desc, max_flips)
 
 
 def _queries(rng, A, kps, n, th=7.0, jitter=6.0):
-    """Queries projected near existing keypoints."""
-    src = rng.integers(0, len(kps), n)
-    q = np.zeros(n, A.QUERY_DTYPE)
-    q["x"] = kps["x"][src] + rng.normal(0, jitter, n).astype(np.float32)
-    q["y"] = kps["y"][src] + rng.normal(0, jitter, n).astype(np.float32)
-    lvl = np.clip(kps["octave"][src] + rng.integers(-1, 2, n), 0, 7).astype(np.int32)
-    q["radius"] = (th * SF[lvl]).astype(np.float32)
-    q["min_level"] = lvl - 1
-    q["max_level"] = lvl
-    return q, lvl, src
+    return synth.projected_queries(rng, kps, n, th, jitter)
 
 
 @pytest.mark.parametrize("seed,use_ur,use_rot,use_marks,max_dist", [
@@ -180,11 +149,7 @@ def test_search_for_initialization(oracle, check_ori):
 
 
 def _featvec(rng, n, n_nodes):
-    node = rng.integers(0, n_nodes, n)
-    order = np.argsort(node, kind="stable")
-    off = np.zeros(n_nodes + 1, np.int32)
-    np.add.at(off, node + 1, 1)
-    return order.astype(np.int32), np.cumsum(off).astype(np.int32)
+    return synth.feature_vector(rng, n, n_nodes)
 
 
 @pytest.mark.parametrize("n_left,check_ori", [(-1, True), (-1, False), (700, True)])
@@ -312,3 +277,35 @@ def test_empty_inputs():
     out, n = m.SearchForInitialization(kps, desc, kps[:0], d0, BOUNDS, prev, 100)
     assert n == 0 and np.all(out == -1)
     A.lib().orbx_release_cached_memory()
+
+
+def test_matchers_against_committed_golden(golden_dir):
+    """The HIP path on the seeded cases of synth.matcher_golden_cases() against tests/golden/matchers.npz."""
+    import os
+    A = _gpu()
+    g = np.load(os.path.join(golden_dir, "matchers.npz"))
+    c = synth.matcher_golden_cases()
+    w = c["window"]
+    bounds = tuple(float(v) for v in w["bounds"])
+    taken = w["taken"].copy()
+    _, kpm, n = A.ORBmatcher(0.9, True).SearchWindowBest(w["kps"], w["desc"], w["ur"], bounds, w["q"], w["qdesc"], 100.0,
+                                                         taken, w["marks"], w["qangle"])
+    assert n == int(g["window_n"]) and np.array_equal(kpm, g["window_kp_match"]) and np.array_equal(taken, g["window_taken"])
+    q = w["q"].copy()
+    q["min_level"], q["max_level"] = w["lvl"] - 1, w["lvl"]
+    m, n = A.ORBmatcher(0.8).SearchByProjection(w["kps"], w["desc"], w["ur"], bounds, q, w["qdesc"], w["taken"].copy())
+    assert n == int(g["projection_n"]) and np.array_equal(m, g["projection_match"])
+    b = c["bow"]
+    m12, n = A.ORBmatcher(0.9, True).SearchByBoWKeyFrames(b["d1"], b["a1"], b["v1"], (b["i1"], b["o1"]), b["d2"], b["a2"],
+                                                          b["v2"], (b["i2"], b["o2"]))
+    assert n == int(g["bow_kf_n"]) and np.array_equal(m12, g["bow_kf_matches12"])
+    mf, n = A.ORBmatcher(0.7, True).SearchByBoW(b["d1"], b["a1"], b["v1"], (b["i1"], b["o1"]), b["d2"], b["a2"],
+                                                (b["i2"], b["o2"]))
+    assert n == int(g["bow_frame_n"]) and np.array_equal(mf, g["bow_frame_match"])
+    v = c["vocabulary"]
+    V = A.Vocabulary(v["child_off"], v["child_idx"], v["node_desc"], v["word_id"], v["weight"], int(v["depth"]))
+    wo, we, ni = V.transform_features(v["features"], 1)
+    assert np.array_equal(wo, g["voc_word"]) and np.array_equal(we, g["voc_weight"]) and np.array_equal(ni, g["voc_node"])
+    d = c["distinctive"]
+    bi, bm = A.distinctive_descriptors(d["desc"], d["off"])
+    assert np.array_equal(bi, g["distinct_idx"]) and np.array_equal(bm, g["distinct_median"])

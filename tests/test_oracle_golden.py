@@ -80,3 +80,19 @@ def test_stereo_golden(oracle, golden_dir):
     disp = kL["x"][m] - uR[m]
     assert np.all(disp > 0) and np.all(disp < fx)
     assert np.allclose(depth[m], mbf / disp, rtol=1e-5)
+
+
+def test_matchers_golden(oracle, golden_dir):
+    """The oracle's matcher loops, vocabulary descent and distinctive-descriptor choice still give the
+    committed results on the seeded cases of synth.matcher_golden_cases()."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(golden_dir), "..", "tools",
+                                                                              "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(golden_dir, "matchers.npz"))
+    now = mg.matcher_outputs(oracle)
+    assert sorted(now) == sorted(g.files)
+    for k in g.files:
+        assert np.array_equal(np.asarray(now[k]), g[k]), k
+    assert int(g["window_n"]) > 100 and int(g["bow_kf_n"]) > 10 and len(np.unique(g["voc_word"])) > 50

@@ -53,6 +53,37 @@ def main():
                         n_left=len(kL), n_right=len(kR), left_crc=np.uint32(synth.checksum(L)),
                         right_crc=np.uint32(synth.checksum(R)))
     print("stereo matches", int((uR >= 0).sum()), "of", len(kL))
+    # the order-dependent matcher loops, the vocabulary descent and the distinctive-descriptor choice
+    np.savez_compressed(os.path.join(OUT, "matchers.npz"), **matcher_outputs(O))
+
+
+def matcher_outputs(O):
+    """Oracle results on synth.matcher_golden_cases()."""
+    c = synth.matcher_golden_cases()
+    out = {}
+    w = c["window"]
+    g = O.Grid(w["kps"], *[float(v) for v in w["bounds"]])
+    q = w["q"]
+    kpm, taken, n = O.search_window_best(g, w["desc"], w["ur"], q["x"], q["y"], q["xr"], q["radius"], q["min_level"],
+                                         q["max_level"], w["qdesc"], 100.0, w["taken"], w["marks"], w["qangle"], 1.0 / 30)
+    out.update(window_kp_match=kpm, window_taken=taken, window_n=np.int32(n))
+    m, _, n = O.search_by_projection(g, w["desc"], w["ur"], q["x"], q["y"], q["xr"], w["lvl"], q["radius"], w["qdesc"],
+                                     w["taken"], 0.8)
+    out.update(projection_match=m, projection_n=np.int32(n))
+    b = c["bow"]
+    m12, n = O.search_by_bow_keyframes(b["d1"], b["a1"], b["v1"], b["i1"], b["o1"], b["d2"], b["a2"], b["v2"], b["i2"],
+                                       b["o2"], 0.9, True)
+    out.update(bow_kf_matches12=m12, bow_kf_n=np.int32(n))
+    mf, n = O.search_by_bow(b["d1"], b["a1"], b["v1"], b["i1"], b["o1"], b["d2"], b["a2"], -1, b["i2"], b["o2"], 0.7, True)
+    out.update(bow_frame_match=mf, bow_frame_n=np.int32(n))
+    v = c["vocabulary"]
+    wo, we, ni = O.bow_transform(v["child_off"], v["child_idx"], v["node_desc"], v["word_id"], v["weight"], int(v["depth"]),
+                                 v["features"], 1)
+    out.update(voc_word=wo, voc_weight=we, voc_node=ni)
+    d = c["distinctive"]
+    bi, bm = O.distinctive_descriptors(d["desc"], d["off"])
+    out.update(distinct_idx=bi, distinct_median=bm)
+    return out
 
 if __name__ == "__main__":
     main()
