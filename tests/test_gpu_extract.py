@@ -183,7 +183,7 @@ def test_batch_equals_single_and_is_deterministic(oracle):
 
 
 def test_full_hd_5000_features(oracle):
-    # BASELINE config 4 frame shape, one frame against the oracle
+    # the batched 1920x1080 / 5000-feature frame shape, one frame against the oracle
     A = _gpu()
     img = synth.scene(1920, 1080, 4, n_prims=1500)
     o = oracle.Extractor(5000)

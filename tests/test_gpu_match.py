@@ -86,7 +86,7 @@ def test_knn2_sharded_merge_equals_single(oracle):
 
 
 def test_knn2_full_size_properties():
-    # BASELINE config 5 shape on one GPU shard: 5000 queries against 1.25 M map descriptors
+    # the large-map search shape on one GPU shard of eight: 5000 queries against 1.25 M map descriptors
     # (one eighth of 10 M).  Too large for the oracle: checked through properties.
     A = _gpu()
     import torch
