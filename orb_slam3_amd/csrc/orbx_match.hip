@@ -158,32 +158,29 @@ __device__ __forceinline__ int knn_dist(const KnnQuery& s, const uint32_t (&t)[8
     return (int)acc;
 }
 
-// kRowsPerIter (= 8) rows against one query: the bookkeeping is entered only when the smallest
-// of the eight distances beats the current second best, and then replays the rows in
-// ascending index order (strict '<' keeps the lowest index among equal distances).
-__device__ __forceinline__ void knn_rows8(KnnQuery& s, const uint32_t (&t)[8][8], int gj) {
-    // the eight accumulator chains advance together, word by word
-    uint32_t acc[8];
+// Four rows against one query: the bookkeeping is entered only when the smallest of the four
+// distances beats the current second best, and then replays the rows in ascending index order
+// (strict '<' keeps the lowest index among equal distances).
+__device__ __forceinline__ void knn_rows4(KnnQuery& s, const uint32_t (&t)[4][8], int gj) {
+    // the four accumulator chains advance together, word by word
+    uint32_t acc[4];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < 4; ++r) {
         const uint32_t x = s.q[0] ^ t[r][0];
         asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(acc[r]) : "v"(x));
     }
 #pragma unroll
     for (int k = 1; k < 8; ++k) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < 4; ++r) {
             const uint32_t x = s.q[k] ^ t[r][k];
             asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[r]) : "v"(x));
         }
     }
-    int d[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) d[r] = (int)acc[r];
-    const int m = min(min(min(d[0], d[1]), min(d[2], d[3])), min(min(d[4], d[5]), min(d[6], d[7])));
+    const int d0 = (int)acc[0], d1 = (int)acc[1], d2 = (int)acc[2], d3 = (int)acc[3];
+    const int m = min(min(d0, d1), min(d2, d3));
     if (m < s.second) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) knn_update(s, d[r], gj + r);
+        knn_update(s, d0, gj); knn_update(s, d1, gj + 1); knn_update(s, d2, gj + 2); knn_update(s, d3, gj + 3);
     }
 }
 
@@ -199,7 +196,7 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restr
                                                           const uint32_t* __restrict__ train, long long nt,
                                                           long long chunkLen, long long baseIndex,
                                                           orbx_match2* __restrict__ part) {
-    static_assert(kQpl == 4 && kRowsPerIter == 8, "the body below is written out for 4 queries x 8 rows");
+    static_assert(kQpl == 4 && kRowsPerIter == 8, "the body below is written out for 4 queries x 2 groups of 4 rows");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int group = blockIdx.x * kKnnWaves + wave;
@@ -215,18 +212,36 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restr
     knn_load(d, query, q0 + 192, nq);
 
     long long j = j0;
-    for (; j + kRowsPerIter <= j1; j += kRowsPerIter) {
-        const uint32_t* __restrict__ t = train + 8ll * j;   // wave-uniform: scalar loads
-        uint32_t tr[8][8];
+    // 8 rows per trip, fetched as two groups of 4: the scalar loads of the second group are in flight
+    // while the first group is applied, and the next trip's first group while the second is applied
+    if (j + kRowsPerIter <= j1) {
+        uint32_t ta[4][8], tb[4][8];
+        {
+            const uint32_t* __restrict__ t = train + 8ll * j;
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) tr[r][k] = t[8 * r + k];
-        const int gj = (int)(baseIndex + j);
-        knn_rows8(a, tr, gj);
-        knn_rows8(b, tr, gj);
-        knn_rows8(c, tr, gj);
-        knn_rows8(d, tr, gj);
+                for (int k = 0; k < 8; ++k) ta[r][k] = t[8 * r + k];
+        }
+        for (; j + kRowsPerIter <= j1; j += kRowsPerIter) {
+            const uint32_t* __restrict__ t = train + 8ll * j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) tb[r][k] = t[32 + 8 * r + k];
+            const int gj = (int)(baseIndex + j);
+            knn_rows4(a, ta, gj); knn_rows4(b, ta, gj); knn_rows4(c, ta, gj); knn_rows4(d, ta, gj);
+            // first group of the next trip.  Scalar loads return out of order, so every wait is for all of them:
+            // wait for the second group here, before the next loads are issued, not at its first use
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+            if (j + 2 * kRowsPerIter <= j1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) ta[r][k] = t[64 + 8 * r + k];
+            }
+            knn_rows4(a, tb, gj + 4); knn_rows4(b, tb, gj + 4); knn_rows4(c, tb, gj + 4); knn_rows4(d, tb, gj + 4);
+        }
     }
     for (; j < j1; ++j) {
         const uint32_t* __restrict__ t = train + 8ll * j;
