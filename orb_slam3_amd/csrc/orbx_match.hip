@@ -260,23 +260,37 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restr
 
 __device__ __forceinline__ bool lex_less(int d0, int i0, int d1, int i1) { return d0 < d1 || (d0 == d1 && i0 < i1); }
 
-__global__ void k_knn2_merge(const orbx_match2* __restrict__ part, int nParts, int nq, orbx_match2* __restrict__ out) {
-    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+// Top-2 fold of two (distance, index) candidates lists in lexicographic order; a missing entry has index -1.
+__device__ __forceinline__ void knn_fold(int& b, int& bi, int& s, int& si, int d, int i) {
+    if (i < 0) return;
+    if (bi < 0 || lex_less(d, i, b, bi)) { s = b; si = bi; b = d; bi = i; }
+    else if (si < 0 || lex_less(d, i, s, si)) { s = d; si = i; }
+}
+
+// One wave per query: the lanes stride over the partial results, then a butterfly folds the 64 lane-local
+// top-2 pairs.  (The lexicographic top-2 of a union is the top-2 of the parts' top-2s, in any grouping.)
+__global__ __launch_bounds__(256) void k_knn2_merge(const orbx_match2* __restrict__ part, int nParts, int nq,
+                                                    orbx_match2* __restrict__ out) {
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (qi >= nq) return;
     int b = INT_MAX, bi = -1, s = INT_MAX, si = -1;
-    for (int p = 0; p < nParts; ++p) {
+    for (int p = lane; p < nParts; p += 64) {
         const orbx_match2 m = part[(long long)p * nq + qi];
-        const int cd[2] = {m.dist0, m.dist1}, ci[2] = {m.idx0, m.idx1};
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            if (ci[e] < 0) continue;
-            if (bi < 0 || lex_less(cd[e], ci[e], b, bi)) { s = b; si = bi; b = cd[e]; bi = ci[e]; }
-            else if (si < 0 || lex_less(cd[e], ci[e], s, si)) { s = cd[e]; si = ci[e]; }
-        }
+        knn_fold(b, bi, s, si, m.dist0, m.idx0);
+        knn_fold(b, bi, s, si, m.dist1, m.idx1);
     }
-    orbx_match2 m;
-    m.idx0 = bi; m.dist0 = b; m.idx1 = si; m.dist1 = s;
-    out[qi] = m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int ob = __shfl_xor(b, off), obi = __shfl_xor(bi, off), os = __shfl_xor(s, off), osi = __shfl_xor(si, off);
+        knn_fold(b, bi, s, si, ob, obi);
+        knn_fold(b, bi, s, si, os, osi);
+    }
+    if (lane == 0) {
+        orbx_match2 m;
+        m.idx0 = bi; m.dist0 = b; m.idx1 = si; m.dist1 = s;
+        out[qi] = m;
+    }
 }
 
 static int knn2_chunks(int nq, long long nt) {
@@ -312,7 +326,7 @@ extern "C" orbx_status orbx_hamming_knn2_device(const uint8_t* d_query, int n_qu
                            (const uint32_t*)d_train, (long long)n_train, chunkLen, (long long)base_index,
                            (orbx_match2*)d_workspace);
     }
-    hipLaunchKernelGGL(k_knn2_merge, dim3((n_query + 255) / 256), dim3(256), 0, st, (const orbx_match2*)d_workspace, chunks,
+    hipLaunchKernelGGL(k_knn2_merge, dim3((n_query + 3) / 4), dim3(256), 0, st, (const orbx_match2*)d_workspace, chunks,
                        n_query, d_out);
     ORBX_HIP_TRY(hipGetLastError());
     return ORBX_OK;
@@ -323,7 +337,7 @@ extern "C" orbx_status orbx_knn2_merge_device(const orbx_match2* d_parts, int n_
     ORBX_REQUIRE(n_parts >= 0 && n_query >= 0, "negative size");
     if (n_query == 0) return ORBX_OK;
     ORBX_REQUIRE(d_parts && d_out, "null argument");
-    hipLaunchKernelGGL(k_knn2_merge, dim3((n_query + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_parts, n_parts,
+    hipLaunchKernelGGL(k_knn2_merge, dim3((n_query + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_parts, n_parts,
                        n_query, d_out);
     ORBX_HIP_TRY(hipGetLastError());
     return ORBX_OK;
