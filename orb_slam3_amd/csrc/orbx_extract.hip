@@ -310,55 +310,82 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
         // (A) quick reject.  An arc of 9 contiguous circle pixels contains one pixel of every
         // antipodal pair, so a corner needs, on one side of the (lower) threshold, a member of
         // {0,8} (the pixels 3 rows below / above) AND a member of {4,12} (3 columns right / left).
-        // The testable pixels are cut into horizontal bands; a lane walks down one column of one
-        // band with that column's 7 rows (y-3 .. y+3) in registers, so each further pixel costs
-        // three LDS byte reads.  Survivors are collected in a per-lane row mask and queued at the
-        // end of the walk (queue order is irrelevant).
-        const int bands = max(1, kFastThreads / iw);
-        const int bandRows = (ih + bands - 1) / bands;
-        const int band = tid / iw, col = tid - band * iw;
-        const bool laneOn = band < bands;
-        const int x = 3 + col;
-        const int yBeg = 3 + band * bandRows;
-        const int yEnd = laneOn ? min(yBeg + bandRows, 3 + ih) : 0;
-        for (int chunk = 0; chunk < bandRows; chunk += 28) {
-            const int yc = yBeg + chunk;                       // first row of this chunk
-            const int rows = min(28, bandRows - chunk);        // uniform
-            const uint8_t* c = T + (laneOn ? yc : 3) * P + (laneOn ? x : 3) - 3;   // 3 left of the centre: offsets stay >= 0
-            int w0 = c[3 - 3 * P], w1 = c[3 - 2 * P], w2 = c[3 - P], w3 = c[3], w4 = c[3 + P], w5 = c[3 + 2 * P], w6 = c[3 + 3 * P];
-            unsigned mask = 0;   // row yc + i of the chunk ends up in bit rows - 1 - i
-            // one row: centre = a3, above = a0, below = a6; afterwards a0 receives row y + 4
-#define ORBX_FAST_ROW(a0, a1, a2, a3, a4, a5, a6, r)                                              \
-            if ((r) < rows) {                                                                         \
-                const int v = a3, lo = v - lowTh, hi = v + lowTh;                                     \
-                const int pl = c[0], pr = c[6];                                                       \
-                const int dmax = max(min(a0, a6), min(pl, pr));   /* dark: both pairs have one < lo */ \
-                const int bmin = min(max(a0, a6), max(pl, pr));   /* bright: both pairs have one > hi */\
-                const bool pass = (dmax < lo) || (bmin > hi);                                         \
-                mask = (mask << 1) | (pass ? 1u : 0u);                                                \
-                c += P;                                                                               \
-                a0 = c[3 + 3 * P];                                                                    \
+        // Four pixels (one tile dword) per lane and step, compared byte-wise with v_lerp_u8:
+        //   lerp(a, ~b, c) = (a - b + 255 + c) >> 1 per byte, so with c chosen to make t + 256 + c even
+        //   "a - b > t"  <=>  lerp(a, ~b, c) >= K := (t + 256 + c) / 2  <=>  bit 7 of lerp(lerp(a, ~b, c), ~K, 1).
+        // The testable pixels are cut into horizontal bands; a lane walks down one dword column of one
+        // band with that column's 7 rows (y-3 .. y+3) in registers, so each further 4 pixels cost three
+        // LDS dword reads.  One wave does the whole cell (fewer instructions than two waves with
+        // shorter bands); survivors are collected in a per-lane nibble mask and queued at the end.
+        if (tid < 64) {
+            const int t1 = lowTh + 1;                                  // a - b >= t1
+            const uint32_t cRound = ((t1 + 255) & 1) ? 0x01010101u : 0u;
+            // K = 256 (threshold 255: nothing can pass) is clamped; the few extra survivors are rejected by (B)
+            const uint32_t K = min((uint32_t)((t1 + 255 + (cRound & 1u)) >> 1), 255u);
+            const uint32_t nK = ~(K * 0x01010101u);
+            const int dFirst = (ox + 3) >> 2, dLast = (ox + 3 + iw - 1) >> 2;     // tile dword columns with testable pixels
+            const int ncol = dLast - dFirst + 1;
+            const int bands = max(1, min(64 / ncol, ih));
+            const int bandRows = (ih + bands - 1) / bands;                      // <= 8 nibbles fit the 32-bit mask when <= 8
+            const int band = tid / ncol, d = dFirst + (tid - band * ncol);
+            const bool laneOn = band < bands;
+            const int yBeg = 3 + band * bandRows;
+            const int yEnd = laneOn ? min(yBeg + bandRows, 3 + ih) : 0;
+            // bytes of this lane's dword that are testable pixels (cell x = 4 d + k - ox in [3, 3 + iw))
+            uint32_t valid = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = 4 * d + k - ox;
+                if (x >= 3 && x < 3 + iw) valid |= 0x80u << (8 * k);
             }
-            for (int r = 0; r < rows; r += 7) {
-                ORBX_FAST_ROW(w0, w1, w2, w3, w4, w5, w6, r + 0)
-                ORBX_FAST_ROW(w1, w2, w3, w4, w5, w6, w0, r + 1)
-                ORBX_FAST_ROW(w2, w3, w4, w5, w6, w0, w1, r + 2)
-                ORBX_FAST_ROW(w3, w4, w5, w6, w0, w1, w2, r + 3)
-                ORBX_FAST_ROW(w4, w5, w6, w0, w1, w2, w3, r + 4)
-                ORBX_FAST_ROW(w5, w6, w0, w1, w2, w3, w4, r + 5)
-                ORBX_FAST_ROW(w6, w0, w1, w2, w3, w4, w5, r + 6)
-            }
-#undef ORBX_FAST_ROW
-            // keep the rows inside the lane's band / the cell: the first `valid` rows of the chunk
-            const int valid = min(yEnd - yc, rows);
-            unsigned m = (valid <= 0) ? 0u : (mask >> (rows - valid));
-            const int cnt = __popc(m);
-            if (cnt) {
-                int base = atomicAdd(&s_nQueue, cnt);
-                while (m) {
-                    const int i = __ffs(m) - 1;       // bit i = row yc + valid - 1 - i
-                    m &= m - 1;
-                    s_queue[base++] = (unsigned short)(x | ((yc + valid - 1 - i) << 7));
+            for (int chunk = 0; chunk < bandRows; chunk += 8) {
+                const int yc = yBeg + chunk;
+                const int rows = min(8, bandRows - chunk);             // uniform
+                const uint32_t* c = reinterpret_cast<const uint32_t*>(tile + (laneOn ? yc : 3) * P) + (laneOn ? d : 1);
+                const int PD = P >> 2;                                 // row pitch in dwords
+                uint32_t w0 = c[-3 * PD], w1 = c[-2 * PD], w2 = c[-PD], w3 = c[0], w4 = c[PD], w5 = c[2 * PD], w6 = c[3 * PD];
+                uint32_t mask = 0;   // row yc + i of the chunk ends up in nibble rows - 1 - i
+#define ORBX_FAST_ROW4(a0, a1, a2, a3, a4, a5, a6, r)                                                       \
+                if ((r) < rows) {                                                                           \
+                    const uint32_t C = a3, nC = ~C;                                                         \
+                    const uint32_t Lw = __builtin_amdgcn_alignbyte(C, c[-1], 1);   /* pixels x - 3 */       \
+                    const uint32_t Rw = __builtin_amdgcn_alignbyte(c[1], C, 3);    /* pixels x + 3 */       \
+                    const uint32_t bU = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(a0, nC, cRound), nK, 0x01010101u); \
+                    const uint32_t bD = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(a6, nC, cRound), nK, 0x01010101u); \
+                    const uint32_t bL = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(Lw, nC, cRound), nK, 0x01010101u); \
+                    const uint32_t bR = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(Rw, nC, cRound), nK, 0x01010101u); \
+                    const uint32_t dU = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(C, ~a0, cRound), nK, 0x01010101u); \
+                    const uint32_t dD = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(C, ~a6, cRound), nK, 0x01010101u); \
+                    const uint32_t dL = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(C, ~Lw, cRound), nK, 0x01010101u); \
+                    const uint32_t dR = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(C, ~Rw, cRound), nK, 0x01010101u); \
+                    const uint32_t F = (((bU | bD) & (bL | bR)) | ((dU | dD) & (dL | dR))) & valid;        \
+                    /* the four flag bits (7, 15, 23, 31) gathered into one nibble */                       \
+                    mask = (mask << 4) | (((F >> 7) * 0x00204081u) >> 21 & 15u);                            \
+                    c += PD;                                                                                \
+                    a0 = c[3 * PD];                                                                         \
+                }
+                for (int r = 0; r < rows; r += 7) {
+                    ORBX_FAST_ROW4(w0, w1, w2, w3, w4, w5, w6, r + 0)
+                    ORBX_FAST_ROW4(w1, w2, w3, w4, w5, w6, w0, r + 1)
+                    ORBX_FAST_ROW4(w2, w3, w4, w5, w6, w0, w1, r + 2)
+                    ORBX_FAST_ROW4(w3, w4, w5, w6, w0, w1, w2, r + 3)
+                    ORBX_FAST_ROW4(w4, w5, w6, w0, w1, w2, w3, r + 4)
+                    ORBX_FAST_ROW4(w5, w6, w0, w1, w2, w3, w4, r + 5)
+                    ORBX_FAST_ROW4(w6, w0, w1, w2, w3, w4, w5, r + 6)
+                }
+#undef ORBX_FAST_ROW4
+                // keep the rows inside the lane's band / the cell: the first `valid` rows of the chunk
+                const int nvalid = min(yEnd - yc, rows);
+                uint32_t m = (nvalid <= 0) ? 0u : (mask >> (4 * (rows - nvalid)));
+                const int cnt = __popc(m);
+                if (cnt) {
+                    int base = atomicAdd(&s_nQueue, cnt);
+                    while (m) {
+                        const int i = __ffs(m) - 1;       // nibble i >> 2 = row yc + nvalid - 1 - (i >> 2), bit i & 3 = byte of the dword
+                        m &= m - 1;
+                        const int x = 4 * d + (i & 3) - ox;
+                        s_queue[base++] = (unsigned short)(x | ((yc + nvalid - 1 - (i >> 2)) << 7));
+                    }
                 }
             }
         }
