@@ -311,6 +311,47 @@ orbx_status orbx_search_for_initialization(const orbx_keypoint* kps1, const uint
                                            float* prev_matched, int window_size, float nn_ratio, int check_orientation,
                                            int* matches12, int* n_matches);
 
+/* ---- frame handle: features resident on the device --------------------------------------
+ * The reference's Frame / KeyFrame keep mvKeysUn, mDescriptors, mvuRight and the 64 x 48 mGrid
+ * for as long as the object lives, and every search of that frame reads them.  An orbx_frame is
+ * the same state on the device: orbx_frame_assign uploads the (undistorted) keypoints,
+ * descriptors and right coordinates once and builds the grid there (Frame::AssignFeaturesToGrid,
+ * Frame.cc:468-506 with PosInGrid :860-870: cell = round((x - min_x) * 64 / (max_x - min_x)),
+ * likewise y; keypoints outside the cells are left out; indices ascend inside a cell).  The
+ * orbx_frame_* searches below are the loops of the functions of the same name without the
+ * "frame" (same arguments, results and order), minus the per-call upload.  The host-array
+ * functions above are these, run on a frame that lives for the call.
+ * A frame is immutable between assigns and may be searched from several threads at once;
+ * assign / destroy need exclusive access.  uright may be NULL (monocular).
+ * orbx_frame_assign_device takes device pointers (for instance the output of
+ * orbx_extract_batch_device and orbx_stereo_match_batch_device for a camera whose keypoints need
+ * no undistortion, Frame.cc:884-888) and copies them; it returns when the copy is complete. */
+typedef struct orbx_frame orbx_frame;
+orbx_status orbx_frame_create(orbx_frame** out);
+void orbx_frame_destroy(orbx_frame* frame);
+orbx_status orbx_frame_assign(orbx_frame* frame, const orbx_keypoint* kps, const uint8_t* desc, const float* uright,
+                              int n_kps, float min_x, float max_x, float min_y, float max_y);
+orbx_status orbx_frame_assign_device(orbx_frame* frame, const orbx_keypoint* d_kps, const uint8_t* d_desc,
+                                     const float* d_uright, int n_kps, float min_x, float max_x, float min_y,
+                                     float max_y);
+int orbx_frame_size(const orbx_frame* frame);
+/* mGrid as CSR (Frame.h:257): cell_start[64 * 48 + 1] with cell = column * 48 + row, cell_idx[]
+ * = keypoint indices, capacity entries; *n_in_grid = keypoints inside the cells. */
+orbx_status orbx_frame_grid(const orbx_frame* frame, int* cell_start, int* cell_idx, int capacity, int* n_in_grid);
+orbx_status orbx_frame_window_candidates(const orbx_frame* frame, const orbx_query* queries, const uint8_t* query_desc,
+                                         int n_query, int* cand_offset, int* cand_idx, int* cand_dist, int capacity,
+                                         int* n_cand_out);
+orbx_status orbx_frame_search_by_projection(const orbx_frame* frame, const orbx_query* queries,
+                                            const uint8_t* query_desc, int n_query, float nn_ratio, uint8_t* taken,
+                                            int* match_out, int* n_matches);
+orbx_status orbx_frame_search_window_best(const orbx_frame* frame, const orbx_query* queries, const uint8_t* query_desc,
+                                          int n_query, float max_dist, uint8_t* taken, const uint8_t* query_marks,
+                                          const float* query_angle, float rot_factor, int* match_out, int* kp_match,
+                                          int* n_matches);
+orbx_status orbx_frame_fuse_search(const orbx_frame* frame, const orbx_query* queries, const uint8_t* query_desc,
+                                   int n_query, const float* inv_level_sigma2, int n_levels, int* match_out,
+                                   int* n_matches);
+
 /* All Hamming distances between the entries of the same vocabulary node of two feature vectors
  * (the inner loops of SearchByBoW / SearchForTriangulation, ORBmatcher.cc:273-363, :856-907,
  * :1030-1078).  Buckets are CSR: entries off[b] .. off[b+1] of idx1 / idx2 are descriptor rows.

@@ -11,6 +11,40 @@
 
 namespace orbx {
 
+// What a Frame / KeyFrame keeps for the windowed searches (mvKeysUn, mDescriptors, mvuRight, mGrid), held on
+// the device; the grid of Frame::AssignFeaturesToGrid (Frame.cc:468-506) is built there.  Assign once per
+// frame, search many times; searches may run from several threads at once.
+class FrameFeatures {
+public:
+    FrameFeatures() { check(orbx_frame_create(&f_)); }
+    FrameFeatures(const std::vector<orbx_keypoint>& keysUn, const std::vector<uint8_t>& descriptors, const float* uRight,
+                  float mnMinX, float mnMaxX, float mnMinY, float mnMaxY) : FrameFeatures() {
+        Assign(keysUn, descriptors, uRight, mnMinX, mnMaxX, mnMinY, mnMaxY);
+    }
+    ~FrameFeatures() { orbx_frame_destroy(f_); }
+    FrameFeatures(const FrameFeatures&) = delete;
+    FrameFeatures& operator=(const FrameFeatures&) = delete;
+
+    void Assign(const std::vector<orbx_keypoint>& keysUn, const std::vector<uint8_t>& descriptors, const float* uRight,
+                float mnMinX, float mnMaxX, float mnMinY, float mnMaxY) {
+        check(orbx_frame_assign(f_, keysUn.data(), descriptors.data(), uRight, (int)keysUn.size(), mnMinX, mnMaxX, mnMinY,
+                                mnMaxY));
+    }
+    int size() const { return orbx_frame_size(f_); }
+    // mGrid as CSR: cellStart[64 * 48 + 1] (cell = column * 48 + row) and the keypoint indices.
+    void Grid(std::vector<int>& cellStart, std::vector<int>& cellIdx) const {
+        int n = 0;
+        cellStart.assign(64 * 48 + 1, 0);
+        cellIdx.assign(size() > 0 ? size() : 1, 0);
+        check(orbx_frame_grid(f_, cellStart.data(), cellIdx.data(), (int)cellIdx.size(), &n));
+        cellIdx.resize(n);
+    }
+    const orbx_frame* handle() const { return f_; }
+
+private:
+    orbx_frame* f_ = nullptr;
+};
+
 class Matcher {
 public:
     static constexpr int TH_LOW = 50;         // ORBmatcher.cc:35
@@ -41,6 +75,17 @@ public:
         return n;
     }
 
+    // The same search on features that are already on the device.
+    int SearchByProjection(const FrameFeatures& F, const std::vector<orbx_query>& projections,
+                           const std::vector<uint8_t>& mapPointDescriptors, std::vector<uint8_t>& taken,
+                           std::vector<int>& matchOut) const {
+        int n = 0;
+        matchOut.assign(projections.size(), -1);
+        check(orbx_frame_search_by_projection(F.handle(), projections.data(), mapPointDescriptors.data(),
+                                              (int)projections.size(), mfNNratio, taken.data(), matchOut.data(), &n));
+        return n;
+    }
+
     // A frame / keyframe side of a windowed search: undistorted keypoints, descriptors, optional right
     // coordinates and the image bounds of its grid (mnMinX, mnMaxX, mnMinY, mnMaxY).
     struct View {
@@ -65,6 +110,29 @@ public:
                                       v.bounds[2], v.bounds[3], queries.data(), queryDescriptors.data(), (int)queries.size(),
                                       maxDist, taken ? taken->data() : nullptr, queryMarks,
                                       mbCheckOrientation ? queryAngles : nullptr, rotFactor, matchOut.data(), kpMatch.data(), &n));
+        return n;
+    }
+
+    int SearchWindowBest(const FrameFeatures& F, const std::vector<orbx_query>& queries,
+                         const std::vector<uint8_t>& queryDescriptors, float maxDist, std::vector<uint8_t>* taken,
+                         const uint8_t* queryMarks, const float* queryAngles, std::vector<int>& matchOut,
+                         std::vector<int>& kpMatch, float rotFactor = 1.0f / HISTO_LENGTH) const {
+        int n = 0;
+        matchOut.assign(queries.size(), -1);
+        kpMatch.assign(F.size(), -1);
+        check(orbx_frame_search_window_best(F.handle(), queries.data(), queryDescriptors.data(), (int)queries.size(), maxDist,
+                                            taken ? taken->data() : nullptr, queryMarks,
+                                            mbCheckOrientation ? queryAngles : nullptr, rotFactor, matchOut.data(),
+                                            kpMatch.data(), &n));
+        return n;
+    }
+
+    int Fuse(const FrameFeatures& F, const std::vector<orbx_query>& queries, const std::vector<uint8_t>& queryDescriptors,
+             const std::vector<float>& invLevelSigma2, std::vector<int>& matchOut) const {
+        int n = 0;
+        matchOut.assign(queries.size(), -1);
+        check(orbx_frame_fuse_search(F.handle(), queries.data(), queryDescriptors.data(), (int)queries.size(),
+                                     invLevelSigma2.data(), (int)invLevelSigma2.size(), matchOut.data(), &n));
         return n;
     }
 

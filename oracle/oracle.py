@@ -74,6 +74,8 @@ def lib():
         L.orc_grid_build.restype = C.c_void_p
         L.orc_grid_build.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
         L.orc_grid_destroy.argtypes = [C.c_void_p]
+        L.orc_grid_csr.restype = C.c_int
+        L.orc_grid_csr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_features_in_area.restype = C.c_int
         L.orc_features_in_area.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_int,
                                            C.c_int, C.c_void_p, C.c_int]
@@ -278,6 +280,13 @@ class Grid:
             lib().orc_grid_destroy(self.g)
         except Exception:
             pass
+
+    def csr(self):
+        """(cell_start[3073], cell_idx[]) with cell = column * 48 + row."""
+        start = np.zeros(64 * 48 + 1, np.int32)
+        idx = np.zeros(max(len(self.kps), 1), np.int32)
+        n = lib().orc_grid_csr(self.g, _p(start), _p(idx), len(idx))
+        return start, idx[:n].copy()
 
     def features_in_area(self, x, y, r, min_level=-1, max_level=-1):
         out = np.zeros(len(self.kps), np.int32)

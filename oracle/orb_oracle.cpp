@@ -882,6 +882,18 @@ void* orc_grid_build(const void* kps_, int n, float minX, float maxX, float minY
     return g;
 }
 void orc_grid_destroy(void* g) { delete (Grid*)g; }
+// The grid as CSR: cell_start[64*48 + 1] (cell = column * 48 + row), cell_idx[] = keypoint indices in
+// insertion order.  Returns the number of keypoints inside the bounds.
+int orc_grid_csr(void* g_, int* cell_start, int* cell_idx, int cap) {
+    const Grid& g = *(Grid*)g_;
+    int n = 0;
+    for (int c = 0; c < 64 * 48; ++c) {
+        cell_start[c] = n;
+        for (int idx : g.cells[c]) { if (n < cap) cell_idx[n] = idx; ++n; }
+    }
+    cell_start[64 * 48] = n;
+    return n;
+}
 int orc_features_in_area(void* g_, const void* kps_, float x, float y, float r, int minLevel, int maxLevel, int* out, int cap) {
     const Grid& g = *(Grid*)g_;
     const KeyPt* k = (const KeyPt*)kps_;

@@ -53,7 +53,7 @@ struct DevBuf {
         if (e == hipSuccess) cap = want; else p = nullptr;
         return e;
     }
-    ~DevBuf() {
+    void release() {
         if (!p) return;
         if (t_cache.cachedBytes + cap <= kCacheLimit) {
             t_cache.free.push_back({p, cap, device});
@@ -61,12 +61,26 @@ struct DevBuf {
         } else {
             (void)hipFree(p);
         }
+        p = nullptr; cap = 0;
     }
+    // keeps the block when it is already large enough (contents are not preserved otherwise)
+    hipError_t ensure(size_t bytes) {
+        if (p && cap >= bytes) return hipSuccess;
+        release();
+        return alloc(bytes);
+    }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
     template <class T> T* as() { return static_cast<T*>(p); }
 };
 }  // namespace
 
+static void release_thread_staging();   // the pinned arena and the scratch frames of the windowed searches
+
 extern "C" void orbx_release_cached_memory(void) {
+    release_thread_staging();
     for (auto& b : t_cache.free) (void)hipFree(b.p);
     t_cache.free.clear();
     t_cache.cachedBytes = 0;
@@ -740,7 +754,8 @@ __global__ __launch_bounds__(256) void k_window(OrbxGridDev g, const orbx_keypoi
                                                 const orbx_query* __restrict__ queries, const uint32_t* __restrict__ qdesc,
                                                 int nq, int mode, int* __restrict__ candCount,
                                                 const int* __restrict__ candOffset, int* __restrict__ candIdx,
-                                                int* __restrict__ candDist, const float* __restrict__ invSigma2) {
+                                                int* __restrict__ candDist, int candCap,
+                                                const float* __restrict__ invSigma2) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= nq) return;
@@ -793,11 +808,13 @@ __global__ __launch_bounds__(256) void k_window(OrbxGridDev g, const orbx_keypoi
                 const unsigned long long bal = __ballot(ok);
                 if (mode == 1 && ok) {
                     const int pos = outBase + total + __popcll(bal & ((1ull << lane) - 1ull));
-                    int d = 0;
+                    if (pos < candCap) {
+                        int d = 0;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) d += __popc(qd[k] ^ desc[8ll * idx + k]);
-                    candIdx[pos] = idx;
-                    candDist[pos] = d;
+                        for (int k = 0; k < 8; ++k) d += __popc(qd[k] ^ desc[8ll * idx + k]);
+                        candIdx[pos] = idx;
+                        candDist[pos] = d;
+                    }
                 }
                 total += __popcll(bal);
             }
@@ -806,92 +823,354 @@ __global__ __launch_bounds__(256) void k_window(OrbxGridDev g, const orbx_keypoi
     if (mode == 0 && lane == 0) candCount[q] = total;
 }
 
-namespace {
-struct HostGrid {
-    std::vector<int> cellStart, cellIdx;
-    float minX, minY, invW, invH;
-};
-// Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:468-506, :860-870): ascending keypoint
-// index inside each cell; keypoints outside the bounds are left out.
-void build_grid(const orbx_keypoint* kps, int n, float minX, float maxX, float minY, float maxY, HostGrid& g) {
-    g.minX = minX; g.minY = minY;
-    g.invW = (float)kGridCols / (maxX - minX);
-    g.invH = (float)kGridRows / (maxY - minY);
-    const int nc = kGridCols * kGridRows;
-    std::vector<int> cell(n, -1);
-    g.cellStart.assign(nc + 1, 0);
-    for (int i = 0; i < n; ++i) {
-        const int px = (int)std::round((kps[i].x - minX) * g.invW);
-        const int py = (int)std::round((kps[i].y - minY) * g.invH);
-        if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) continue;
-        cell[i] = px * kGridRows + py;
-        ++g.cellStart[cell[i] + 1];
+// ======================================================================================
+// Frame handle: the features of one image resident on the device, with the 64 x 48 grid of
+// Frame::AssignFeaturesToGrid built there.  Every windowed search of the frame reuses it.
+// ======================================================================================
+constexpr int kGridCells = kGridCols * kGridRows;
+constexpr int kGridThreads = 1024;
+constexpr int kCellsPerThread = kGridCells / kGridThreads;
+static_assert(kCellsPerThread * kGridThreads == kGridCells, "each thread owns a whole number of grid cells");
+
+// Exclusive prefix of `v` over the workgroup (kGridThreads lanes); *total = the sum.
+__device__ __forceinline__ int block_exclusive_scan(int v, int* s_wave /* kGridThreads / 64 */, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
     }
-    for (int c = 0; c < nc; ++c) g.cellStart[c + 1] += g.cellStart[c];
-    g.cellIdx.assign(g.cellStart[nc], 0);
-    std::vector<int> cur(g.cellStart.begin(), g.cellStart.end() - 1);
-    for (int i = 0; i < n; ++i)
-        if (cell[i] >= 0) g.cellIdx[cur[cell[i]]++] = i;
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    int before = 0, all = 0;
+    for (int w = 0; w < kGridThreads / 64; ++w) {
+        const int t = s_wave[w];
+        if (w < wave) before += t;
+        all += t;
+    }
+    __syncthreads();
+    *total = all;
+    return before + inc - v;
+}
+
+// Frame::AssignFeaturesToGrid + PosInGrid (Frame.cc:468-506, :860-870) in one workgroup:
+// cell = (round((x - minX) * invW), round((y - minY) * invH)); keypoints outside the 64 x 48
+// cells are left out; inside a cell the indices ascend (the reference appends in index order).
+// Output is CSR: cellStart[kGridCells + 1] with cell = column * 48 + row, and cellIdx[].
+__global__ __launch_bounds__(kGridThreads) void k_assign_grid(const orbx_keypoint* __restrict__ kps, int n, float minX,
+                                                              float minY, float invW, float invH,
+                                                              int* __restrict__ cellStart, int* __restrict__ cellIdx) {
+    __shared__ int s_cell[kGridCells];   // counts, then fill cursors
+    __shared__ int s_wave[kGridThreads / 64];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < kGridCells; c += kGridThreads) s_cell[c] = 0;
+    __syncthreads();
+    auto cell_of = [&](int i) {
+        const int px = (int)roundf(__fmul_rn(__fsub_rn(kps[i].x, minX), invW));
+        const int py = (int)roundf(__fmul_rn(__fsub_rn(kps[i].y, minY), invH));
+        return (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? -1 : px * kGridRows + py;
+    };
+    for (int i = tid; i < n; i += kGridThreads) {
+        const int c = cell_of(i);
+        if (c >= 0) atomicAdd(&s_cell[c], 1);
+    }
+    __syncthreads();
+    int cnt[kCellsPerThread], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kCellsPerThread; ++k) { cnt[k] = s_cell[tid * kCellsPerThread + k]; sum += cnt[k]; }
+    int total;
+    int start = block_exclusive_scan(sum, s_wave, &total);
+    int first[kCellsPerThread];
+#pragma unroll
+    for (int k = 0; k < kCellsPerThread; ++k) {
+        first[k] = start;
+        cellStart[tid * kCellsPerThread + k] = start;
+        s_cell[tid * kCellsPerThread + k] = start;
+        start += cnt[k];
+    }
+    if (tid == 0) cellStart[kGridCells] = total;
+    __syncthreads();
+    for (int i = tid; i < n; i += kGridThreads) {
+        const int c = cell_of(i);
+        if (c >= 0) cellIdx[atomicAdd(&s_cell[c], 1)] = i;
+    }
+    __syncthreads();   // the fill is complete and visible to the whole workgroup
+    // the atomics filled each cell in arbitrary order: sort the (short) cells ascending
+#pragma unroll
+    for (int k = 0; k < kCellsPerThread; ++k) {
+        const int b = first[k], e = b + cnt[k];
+        for (int i = b + 1; i < e; ++i) {
+            const int v = cellIdx[i];
+            int j = i - 1;
+            while (j >= b && cellIdx[j] > v) { cellIdx[j + 1] = cellIdx[j]; --j; }
+            cellIdx[j + 1] = v;
+        }
+    }
+}
+
+// off[0..n] = exclusive prefix sums of count[0..n), written to two places (a device copy for
+// the kernel that follows and a host-visible copy).  One workgroup.
+__global__ __launch_bounds__(kGridThreads) void k_exclusive_scan(const int* __restrict__ count, int n,
+                                                                 int* __restrict__ offA, int* __restrict__ offB) {
+    __shared__ int s_wave[kGridThreads / 64];
+    const int per = (n + kGridThreads - 1) / kGridThreads;
+    const int b = min(n, (int)threadIdx.x * per), e = min(n, b + per);
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += count[i];
+    int total;
+    int run = block_exclusive_scan(sum, s_wave, &total);
+    for (int i = b; i < e; ++i) { offA[i] = run; offB[i] = run; run += count[i]; }
+    if (threadIdx.x == 0) { offA[n] = total; offB[n] = total; }
+}
+
+namespace {
+// Host memory the device reads and writes in place (queries in, candidate lists out): a search
+// is three kernel launches and one stream synchronisation, with no copy commands in between.
+// One arena and one stream per host thread; both live until orbx_release_cached_memory().
+struct PinnedArena {
+    char* host = nullptr;
+    char* dev = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        release();
+        size_t want = (size_t)1 << 20;
+        while (want < bytes) want <<= 1;
+        void* h = nullptr;
+        hipError_t e = hipHostMalloc(&h, want, hipHostMallocPortable | hipHostMallocMapped);
+        if (e != hipSuccess) return e;
+        void* d = nullptr;
+        e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) { (void)hipHostFree(h); return e; }
+        host = static_cast<char*>(h); dev = static_cast<char*>(d); cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (host) (void)hipHostFree(host);
+        host = dev = nullptr; cap = 0;
+    }
+};
+thread_local PinnedArena t_arena;
+constexpr int kMaxDevices = 16;
+thread_local hipStream_t t_streams[kMaxDevices] = {};
+
+hipError_t thread_stream(hipStream_t* out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) { *out = nullptr; return hipSuccess; }   // the default stream
+    if (!t_streams[dev]) {
+        e = hipStreamCreateWithFlags(&t_streams[dev], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *out = t_streams[dev];
+    return hipSuccess;
 }
 }  // namespace
 
-static orbx_status window_candidates_impl(const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps,
-                                          float min_x, float max_x, float min_y, float max_y, const orbx_query* queries,
-                                          const uint8_t* query_desc, int n_query, std::vector<int>& offset,
-                                          std::vector<int>& idx, std::vector<int>& dist,
-                                          const float* inv_sigma2 = nullptr, int n_levels = 0) {
-    ORBX_REQUIRE(n_kps >= 0 && n_query >= 0, "negative size");
+struct orbx_frame {
+    int n = 0;
+    bool hasUright = false;
+    float minX = 0, maxX = 0, minY = 0, maxY = 0, invW = 0, invH = 0;
+    DevBuf kps, desc, uright, cellStart, cellIdx;
+    std::vector<orbx_keypoint> hostKps;   // what the in-order loops read (level, angle, position)
+};
+
+namespace {
+// Candidate lists of one search; they point into the calling thread's arena and stay valid until
+// that thread's next search.
+struct WindowLists {
+    const int* off = nullptr;
+    const int* idx = nullptr;
+    const int* dist = nullptr;
+    std::vector<int> none;   // offsets of a search without queries or keypoints
+    void set_empty(int nq) { none.assign((size_t)nq + 1, 0); off = none.data(); idx = dist = nullptr; }
+};
+
+orbx_status frame_set_bounds(orbx_frame& F, float min_x, float max_x, float min_y, float max_y) {
     ORBX_REQUIRE(max_x > min_x && max_y > min_y, "empty image bounds");
-    offset.assign(n_query + 1, 0);
-    idx.clear(); dist.clear();
-    if (n_query == 0 || n_kps == 0) return ORBX_OK;
-    ORBX_REQUIRE(kps && desc && queries && query_desc, "null argument");
-    HostGrid hg;
-    build_grid(kps, n_kps, min_x, max_x, min_y, max_y, hg);
-    DevBuf dStart, dIdx, dKps, dDesc, dUr, dQ, dQd, dCount, dOff, dCi, dCd;
-    ORBX_HIP_TRY(dStart.alloc(hg.cellStart.size() * 4)); ORBX_HIP_TRY(dIdx.alloc(hg.cellIdx.size() * 4));
-    ORBX_HIP_TRY(dKps.alloc((size_t)n_kps * sizeof(orbx_keypoint))); ORBX_HIP_TRY(dDesc.alloc((size_t)n_kps * 32));
-    ORBX_HIP_TRY(dUr.alloc((size_t)n_kps * 4));
-    ORBX_HIP_TRY(dQ.alloc((size_t)n_query * sizeof(orbx_query))); ORBX_HIP_TRY(dQd.alloc((size_t)n_query * 32));
-    ORBX_HIP_TRY(dCount.alloc((size_t)n_query * 4)); ORBX_HIP_TRY(dOff.alloc((size_t)(n_query + 1) * 4));
-    DevBuf dSig;
-    if (inv_sigma2) {
-        ORBX_REQUIRE(n_levels > 0, "inv_level_sigma2 without levels");
-        for (int i = 0; i < n_kps; ++i)
-            ORBX_REQUIRE(kps[i].octave >= 0 && kps[i].octave < n_levels, "keypoint %d: octave %d outside the %d levels", i, kps[i].octave, n_levels);
-        ORBX_HIP_TRY(dSig.alloc((size_t)n_levels * 4));
-        ORBX_HIP_TRY(hipMemcpy(dSig.p, inv_sigma2, (size_t)n_levels * 4, hipMemcpyHostToDevice));
-    }
-    ORBX_HIP_TRY(hipMemcpy(dStart.p, hg.cellStart.data(), hg.cellStart.size() * 4, hipMemcpyHostToDevice));
-    if (!hg.cellIdx.empty()) ORBX_HIP_TRY(hipMemcpy(dIdx.p, hg.cellIdx.data(), hg.cellIdx.size() * 4, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(dKps.p, kps, (size_t)n_kps * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(dDesc.p, desc, (size_t)n_kps * 32, hipMemcpyHostToDevice));
-    if (uright) ORBX_HIP_TRY(hipMemcpy(dUr.p, uright, (size_t)n_kps * 4, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(dQ.p, queries, (size_t)n_query * sizeof(orbx_query), hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(dQd.p, query_desc, (size_t)n_query * 32, hipMemcpyHostToDevice));
-    OrbxGridDev g;
-    g.cellStart = dStart.as<int>(); g.cellIdx = dIdx.as<int>();
-    g.minX = hg.minX; g.minY = hg.minY; g.invW = hg.invW; g.invH = hg.invH;
-    const dim3 grid((n_query + 3) / 4), block(256);
-    hipLaunchKernelGGL(k_window, grid, block, 0, 0, g, dKps.as<orbx_keypoint>(), dDesc.as<uint32_t>(),
-                       uright ? dUr.as<float>() : nullptr, dQ.as<orbx_query>(), dQd.as<uint32_t>(), n_query, 0,
-                       dCount.as<int>(), nullptr, nullptr, nullptr, inv_sigma2 ? dSig.as<float>() : nullptr);
-    ORBX_HIP_TRY(hipGetLastError());
-    std::vector<int> count(n_query);
-    ORBX_HIP_TRY(hipMemcpy(count.data(), dCount.p, (size_t)n_query * 4, hipMemcpyDeviceToHost));
-    for (int q = 0; q < n_query; ++q) offset[q + 1] = offset[q] + count[q];
-    const int total = offset[n_query];
-    idx.assign(total, 0); dist.assign(total, 0);
-    if (total == 0) return ORBX_OK;
-    ORBX_HIP_TRY(dCi.alloc((size_t)total * 4)); ORBX_HIP_TRY(dCd.alloc((size_t)total * 4));
-    ORBX_HIP_TRY(hipMemcpy(dOff.p, offset.data(), (size_t)(n_query + 1) * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_window, grid, block, 0, 0, g, dKps.as<orbx_keypoint>(), dDesc.as<uint32_t>(),
-                       uright ? dUr.as<float>() : nullptr, dQ.as<orbx_query>(), dQd.as<uint32_t>(), n_query, 1,
-                       nullptr, dOff.as<int>(), dCi.as<int>(), dCd.as<int>(), inv_sigma2 ? dSig.as<float>() : nullptr);
-    ORBX_HIP_TRY(hipGetLastError());
-    ORBX_HIP_TRY(hipMemcpy(idx.data(), dCi.p, (size_t)total * 4, hipMemcpyDeviceToHost));
-    ORBX_HIP_TRY(hipMemcpy(dist.data(), dCd.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    F.minX = min_x; F.maxX = max_x; F.minY = min_y; F.maxY = max_y;
+    F.invW = (float)kGridCols / (max_x - min_x);     // mfGridElementWidthInv (Frame.cc:127-128)
+    F.invH = (float)kGridRows / (max_y - min_y);
     return ORBX_OK;
+}
+
+// Uploads (or copies, for device sources) the features and builds the grid.
+orbx_status frame_assign(orbx_frame& F, const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n,
+                         float min_x, float max_x, float min_y, float max_y, bool fromDevice) {
+    ORBX_REQUIRE(n >= 0, "negative size");
+    ORBX_REQUIRE(n == 0 || (kps && desc), "null argument");
+    orbx_status s = frame_set_bounds(F, min_x, max_x, min_y, max_y);
+    if (s != ORBX_OK) return s;
+    F.n = n;
+    F.hasUright = uright != nullptr;
+    F.hostKps.resize(n);
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
+    ORBX_HIP_TRY(F.cellStart.ensure((size_t)(kGridCells + 1) * 4));
+    ORBX_HIP_TRY(F.cellIdx.ensure((size_t)std::max(n, 1) * 4));
+    ORBX_HIP_TRY(F.kps.ensure((size_t)std::max(n, 1) * sizeof(orbx_keypoint)));
+    ORBX_HIP_TRY(F.desc.ensure((size_t)std::max(n, 1) * 32));
+    if (uright) ORBX_HIP_TRY(F.uright.ensure((size_t)std::max(n, 1) * 4));
+    if (n > 0) {
+        const hipMemcpyKind kind = fromDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        ORBX_HIP_TRY(hipMemcpyAsync(F.kps.p, kps, (size_t)n * sizeof(orbx_keypoint), kind, st));
+        ORBX_HIP_TRY(hipMemcpyAsync(F.desc.p, desc, (size_t)n * 32, kind, st));
+        if (uright) ORBX_HIP_TRY(hipMemcpyAsync(F.uright.p, uright, (size_t)n * 4, kind, st));
+        if (fromDevice)
+            ORBX_HIP_TRY(hipMemcpyAsync(F.hostKps.data(), kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, st));
+        else
+            memcpy(F.hostKps.data(), kps, (size_t)n * sizeof(orbx_keypoint));
+    }
+    hipLaunchKernelGGL(k_assign_grid, dim3(1), dim3(kGridThreads), 0, st, F.kps.as<orbx_keypoint>(), n, F.minX, F.minY,
+                       F.invW, F.invH, F.cellStart.as<int>(), F.cellIdx.as<int>());
+    ORBX_HIP_TRY(hipGetLastError());
+    ORBX_HIP_TRY(hipStreamSynchronize(st));
+    return ORBX_OK;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// GetFeaturesInArea for every query + the Hamming distance of every returned keypoint.
+orbx_status frame_window_lists(const orbx_frame& F, const orbx_query* queries, const uint8_t* query_desc, int n_query,
+                               WindowLists& L, const float* inv_sigma2 = nullptr, int n_levels = 0) {
+    ORBX_REQUIRE(n_query >= 0, "negative size");
+    if (n_query == 0 || F.n == 0) { L.set_empty(n_query); return ORBX_OK; }
+    ORBX_REQUIRE(queries && query_desc, "null argument");
+    if (inv_sigma2) {
+        ORBX_REQUIRE(n_levels > 0 && n_levels <= 64, "inv_level_sigma2 needs 1..64 levels");
+        for (int i = 0; i < F.n; ++i)
+            ORBX_REQUIRE(F.hostKps[i].octave >= 0 && F.hostKps[i].octave < n_levels,
+                         "keypoint %d: octave %d outside the %d levels", i, F.hostKps[i].octave, n_levels);
+    }
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
+    const size_t oQ = 0, oQd = align256(oQ + (size_t)n_query * sizeof(orbx_query));
+    const size_t oSig = align256(oQd + (size_t)n_query * 32), oOff = oSig + 256;
+    const size_t oCand = align256(oOff + (size_t)(n_query + 1) * 4);
+    DevBuf dCount, dOff;
+    ORBX_HIP_TRY(dCount.alloc((size_t)n_query * 4));
+    ORBX_HIP_TRY(dOff.alloc((size_t)(n_query + 1) * 4));
+    OrbxGridDev g;
+    g.cellStart = F.cellStart.p ? static_cast<const int*>(F.cellStart.p) : nullptr;
+    g.cellIdx = static_cast<const int*>(F.cellIdx.p);
+    g.minX = F.minX; g.minY = F.minY; g.invW = F.invW; g.invH = F.invH;
+    const orbx_keypoint* dKps = static_cast<const orbx_keypoint*>(F.kps.p);
+    const uint32_t* dDesc = static_cast<const uint32_t*>(F.desc.p);
+    const float* dUr = F.hasUright ? static_cast<const float*>(F.uright.p) : nullptr;
+    const dim3 grid((n_query + 3) / 4), block(256);
+    size_t want = oCand + (size_t)n_query * 32 * 8;   // first guess: 32 candidates per query
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        ORBX_HIP_TRY(t_arena.ensure(want));
+        char* h = t_arena.host;
+        char* d = t_arena.dev;
+        const int cap = (int)std::min<size_t>((t_arena.cap - oCand) / 8, (size_t)INT_MAX / 2);
+        memcpy(h + oQ, queries, (size_t)n_query * sizeof(orbx_query));
+        memcpy(h + oQd, query_desc, (size_t)n_query * 32);
+        if (inv_sigma2) memcpy(h + oSig, inv_sigma2, (size_t)n_levels * 4);
+        const orbx_query* dQ = reinterpret_cast<const orbx_query*>(d + oQ);
+        const uint32_t* dQd = reinterpret_cast<const uint32_t*>(d + oQd);
+        const float* dSig = inv_sigma2 ? reinterpret_cast<const float*>(d + oSig) : nullptr;
+        int* dCi = reinterpret_cast<int*>(d + oCand);
+        int* dCd = dCi + cap;
+        hipLaunchKernelGGL(k_window, grid, block, 0, st, g, dKps, dDesc, dUr, dQ, dQd, n_query, 0, dCount.as<int>(),
+                           nullptr, nullptr, nullptr, 0, dSig);
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(kGridThreads), 0, st, dCount.as<int>(), n_query,
+                           dOff.as<int>(), reinterpret_cast<int*>(d + oOff));
+        hipLaunchKernelGGL(k_window, grid, block, 0, st, g, dKps, dDesc, dUr, dQ, dQd, n_query, 1, nullptr,
+                           dOff.as<int>(), dCi, dCd, cap, dSig);
+        ORBX_HIP_TRY(hipGetLastError());
+        ORBX_HIP_TRY(hipStreamSynchronize(st));
+        const int* off = reinterpret_cast<const int*>(h + oOff);
+        const int total = off[n_query];
+        if (total <= cap) {
+            L.off = off;
+            L.idx = reinterpret_cast<const int*>(h + oCand);
+            L.dist = L.idx + cap;
+            return ORBX_OK;
+        }
+        want = oCand + (size_t)total * 8;   // the lists did not fit: once more with room for all of them
+    }
+    orbx_set_error("candidate lists did not fit after growing the staging arena");
+    return ORBX_ERR_CAPACITY;
+}
+
+thread_local orbx_frame* t_scratchFrame[2] = {nullptr, nullptr};
+
+// The searches that take plain host arrays build a frame of the calling thread for the duration of the call.
+orbx_status scratch_frame(const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps, float min_x,
+                          float max_x, float min_y, float max_y, orbx_frame** out, int slot = 0) {
+    if (!t_scratchFrame[slot]) t_scratchFrame[slot] = new orbx_frame;
+    *out = t_scratchFrame[slot];
+    return frame_assign(**out, kps, desc, uright, n_kps, min_x, max_x, min_y, max_y, false);
+}
+
+orbx_status copy_lists_out(const WindowLists& L, int n_query, int* cand_offset, int* cand_idx, int* cand_dist,
+                           int capacity, int* n_cand_out) {
+    memcpy(cand_offset, L.off, ((size_t)n_query + 1) * sizeof(int));
+    const int total = L.off[n_query];
+    *n_cand_out = total;
+    if (total > capacity) { orbx_set_error("%d candidates, capacity %d", total, capacity); return ORBX_ERR_CAPACITY; }
+    if (total > 0) {
+        ORBX_REQUIRE(cand_idx && cand_dist, "null argument");
+        memcpy(cand_idx, L.idx, (size_t)total * sizeof(int));
+        memcpy(cand_dist, L.dist, (size_t)total * sizeof(int));
+    }
+    return ORBX_OK;
+}
+}  // namespace
+
+static void release_thread_staging() {
+    for (auto*& f : t_scratchFrame) { delete f; f = nullptr; }
+    t_arena.release();
+}
+
+extern "C" orbx_status orbx_frame_create(orbx_frame** out) {
+    ORBX_REQUIRE(out, "null argument");
+    *out = new orbx_frame;
+    return ORBX_OK;
+}
+
+extern "C" void orbx_frame_destroy(orbx_frame* f) { delete f; }
+
+extern "C" orbx_status orbx_frame_assign(orbx_frame* f, const orbx_keypoint* kps, const uint8_t* desc, const float* uright,
+                                         int n, float min_x, float max_x, float min_y, float max_y) {
+    ORBX_REQUIRE(f, "null frame");
+    return frame_assign(*f, kps, desc, uright, n, min_x, max_x, min_y, max_y, false);
+}
+
+extern "C" orbx_status orbx_frame_assign_device(orbx_frame* f, const orbx_keypoint* d_kps, const uint8_t* d_desc,
+                                                const float* d_uright, int n, float min_x, float max_x, float min_y,
+                                                float max_y) {
+    ORBX_REQUIRE(f, "null frame");
+    return frame_assign(*f, d_kps, d_desc, d_uright, n, min_x, max_x, min_y, max_y, true);
+}
+
+extern "C" int orbx_frame_size(const orbx_frame* f) { return f ? f->n : 0; }
+
+extern "C" orbx_status orbx_frame_grid(const orbx_frame* f, int* cell_start, int* cell_idx, int capacity,
+                                       int* n_in_grid) {
+    ORBX_REQUIRE(f && cell_start && n_in_grid, "null argument");
+    ORBX_REQUIRE(f->cellStart.p, "frame has no features yet");
+    ORBX_HIP_TRY(hipMemcpy(cell_start, f->cellStart.p, (size_t)(kGridCells + 1) * 4, hipMemcpyDeviceToHost));
+    *n_in_grid = cell_start[kGridCells];
+    if (*n_in_grid > capacity) { orbx_set_error("%d keypoints in the grid, capacity %d", *n_in_grid, capacity); return ORBX_ERR_CAPACITY; }
+    if (*n_in_grid > 0) {
+        ORBX_REQUIRE(cell_idx, "null argument");
+        ORBX_HIP_TRY(hipMemcpy(cell_idx, f->cellIdx.p, (size_t)*n_in_grid * 4, hipMemcpyDeviceToHost));
+    }
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_frame_window_candidates(const orbx_frame* f, const orbx_query* queries,
+                                                    const uint8_t* query_desc, int n_query, int* cand_offset,
+                                                    int* cand_idx, int* cand_dist, int capacity, int* n_cand_out) {
+    ORBX_REQUIRE(f && cand_offset && n_cand_out, "null argument");
+    WindowLists L;
+    orbx_status s = frame_window_lists(*f, queries, query_desc, n_query, L);
+    if (s != ORBX_OK) return s;
+    return copy_lists_out(L, n_query, cand_offset, cand_idx, cand_dist, capacity, n_cand_out);
 }
 
 extern "C" orbx_status orbx_window_candidates(const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps,
@@ -899,31 +1178,22 @@ extern "C" orbx_status orbx_window_candidates(const orbx_keypoint* kps, const ui
                                               const orbx_query* queries, const uint8_t* query_desc, int n_query,
                                               int* cand_offset, int* cand_idx, int* cand_dist, int capacity,
                                               int* n_cand_out) {
-    ORBX_REQUIRE(cand_offset && n_cand_out, "null argument");
-    std::vector<int> off, idx, dist;
-    orbx_status s = window_candidates_impl(kps, desc, uright, n_kps, min_x, max_x, min_y, max_y, queries, query_desc,
-                                           n_query, off, idx, dist);
+    orbx_frame* F;
+    orbx_status s = scratch_frame(kps, desc, uright, n_kps, min_x, max_x, min_y, max_y, &F);
     if (s != ORBX_OK) return s;
-    memcpy(cand_offset, off.data(), off.size() * sizeof(int));
-    *n_cand_out = (int)idx.size();
-    if ((int)idx.size() > capacity) { orbx_set_error("%zu candidates, capacity %d", idx.size(), capacity); return ORBX_ERR_CAPACITY; }
-    if (!idx.empty()) {
-        ORBX_REQUIRE(cand_idx && cand_dist, "null argument");
-        memcpy(cand_idx, idx.data(), idx.size() * sizeof(int));
-        memcpy(cand_dist, dist.data(), dist.size() * sizeof(int));
-    }
-    return ORBX_OK;
+    return orbx_frame_window_candidates(F, queries, query_desc, n_query, cand_offset, cand_idx, cand_dist, capacity,
+                                        n_cand_out);
 }
 
-extern "C" orbx_status orbx_search_by_projection(const orbx_keypoint* kps, const uint8_t* desc, const float* uright,
-                                                 int n_kps, float min_x, float max_x, float min_y, float max_y,
-                                                 const orbx_query* queries, const uint8_t* query_desc, int n_query,
-                                                 float nn_ratio, uint8_t* taken, int* match_out, int* n_matches) {
-    ORBX_REQUIRE(match_out && n_matches && (n_kps == 0 || taken), "null argument");
-    std::vector<int> off, idx, dist;
-    orbx_status s = window_candidates_impl(kps, desc, uright, n_kps, min_x, max_x, min_y, max_y, queries, query_desc,
-                                           n_query, off, idx, dist);
+extern "C" orbx_status orbx_frame_search_by_projection(const orbx_frame* f, const orbx_query* queries,
+                                                       const uint8_t* query_desc, int n_query, float nn_ratio,
+                                                       uint8_t* taken, int* match_out, int* n_matches) {
+    ORBX_REQUIRE(f && n_matches && (n_query == 0 || match_out) && (f->n == 0 || taken), "null argument");
+    const orbx_keypoint* kps = f->hostKps.data();
+    WindowLists L;
+    orbx_status s = frame_window_lists(*f, queries, query_desc, n_query, L);
     if (s != ORBX_OK) return s;
+    const int *off = L.off, *idx = L.idx, *dist = L.dist;
     // Greedy resolve in query order (ORBmatcher.cc:84-141): a keypoint matched by an
     // earlier map point is skipped by the later ones.
     int nm = 0;
@@ -949,6 +1219,16 @@ extern "C" orbx_status orbx_search_by_projection(const orbx_keypoint* kps, const
     }
     *n_matches = nm;
     return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_search_by_projection(const orbx_keypoint* kps, const uint8_t* desc, const float* uright,
+                                                 int n_kps, float min_x, float max_x, float min_y, float max_y,
+                                                 const orbx_query* queries, const uint8_t* query_desc, int n_query,
+                                                 float nn_ratio, uint8_t* taken, int* match_out, int* n_matches) {
+    orbx_frame* F;
+    orbx_status s = scratch_frame(kps, desc, uright, n_kps, min_x, max_x, min_y, max_y, &F);
+    if (s != ORBX_OK) return s;
+    return orbx_frame_search_by_projection(F, queries, query_desc, n_query, nn_ratio, taken, match_out, n_matches);
 }
 
 // ======================================================================================
@@ -1066,17 +1346,18 @@ struct RotHist {
 };
 }  // namespace
 
-extern "C" orbx_status orbx_search_window_best(const orbx_keypoint* kps, const uint8_t* desc, const float* uright,
-                                               int n_kps, float min_x, float max_x, float min_y, float max_y,
-                                               const orbx_query* queries, const uint8_t* query_desc, int n_query,
-                                               float max_dist, uint8_t* taken, const uint8_t* query_marks,
-                                               const float* query_angle, float rot_factor, int* match_out,
-                                               int* kp_match, int* n_matches) {
-    ORBX_REQUIRE(n_matches && (n_query == 0 || match_out) && (n_kps == 0 || kp_match), "null argument");
-    std::vector<int> off, idx, dist;
-    orbx_status s = window_candidates_impl(kps, desc, uright, n_kps, min_x, max_x, min_y, max_y, queries, query_desc,
-                                           n_query, off, idx, dist);
+extern "C" orbx_status orbx_frame_search_window_best(const orbx_frame* f, const orbx_query* queries,
+                                                     const uint8_t* query_desc, int n_query, float max_dist,
+                                                     uint8_t* taken, const uint8_t* query_marks,
+                                                     const float* query_angle, float rot_factor, int* match_out,
+                                                     int* kp_match, int* n_matches) {
+    ORBX_REQUIRE(f && n_matches && (n_query == 0 || match_out) && (f->n == 0 || kp_match), "null argument");
+    const orbx_keypoint* kps = f->hostKps.data();
+    const int n_kps = f->n;
+    WindowLists L;
+    orbx_status s = frame_window_lists(*f, queries, query_desc, n_query, L);
     if (s != ORBX_OK) return s;
+    const int *off = L.off, *idx = L.idx, *dist = L.dist;
     for (int i = 0; i < n_kps; ++i) kp_match[i] = -1;
     RotHist hist(rot_factor);
     int nm = 0;
@@ -1104,15 +1385,27 @@ extern "C" orbx_status orbx_search_window_best(const orbx_keypoint* kps, const u
     return ORBX_OK;
 }
 
-extern "C" orbx_status orbx_fuse_search(const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps,
-                                        float min_x, float max_x, float min_y, float max_y, const orbx_query* queries,
-                                        const uint8_t* query_desc, int n_query, const float* inv_level_sigma2,
-                                        int n_levels, int* match_out, int* n_matches) {
-    ORBX_REQUIRE(n_matches && (n_query == 0 || match_out) && inv_level_sigma2, "null argument");
-    std::vector<int> off, idx, dist;
-    orbx_status s = window_candidates_impl(kps, desc, uright, n_kps, min_x, max_x, min_y, max_y, queries, query_desc,
-                                           n_query, off, idx, dist, inv_level_sigma2, n_levels);
+extern "C" orbx_status orbx_search_window_best(const orbx_keypoint* kps, const uint8_t* desc, const float* uright,
+                                               int n_kps, float min_x, float max_x, float min_y, float max_y,
+                                               const orbx_query* queries, const uint8_t* query_desc, int n_query,
+                                               float max_dist, uint8_t* taken, const uint8_t* query_marks,
+                                               const float* query_angle, float rot_factor, int* match_out,
+                                               int* kp_match, int* n_matches) {
+    orbx_frame* F;
+    orbx_status s = scratch_frame(kps, desc, uright, n_kps, min_x, max_x, min_y, max_y, &F);
     if (s != ORBX_OK) return s;
+    return orbx_frame_search_window_best(F, queries, query_desc, n_query, max_dist, taken, query_marks, query_angle,
+                                         rot_factor, match_out, kp_match, n_matches);
+}
+
+extern "C" orbx_status orbx_frame_fuse_search(const orbx_frame* f, const orbx_query* queries, const uint8_t* query_desc,
+                                              int n_query, const float* inv_level_sigma2, int n_levels, int* match_out,
+                                              int* n_matches) {
+    ORBX_REQUIRE(f && n_matches && (n_query == 0 || match_out) && inv_level_sigma2, "null argument");
+    WindowLists L;
+    orbx_status s = frame_window_lists(*f, queries, query_desc, n_query, L, inv_level_sigma2, n_levels);
+    if (s != ORBX_OK) return s;
+    const int *off = L.off, *idx = L.idx, *dist = L.dist;
     int nm = 0;
     for (int q = 0; q < n_query; ++q) {
         int best = 256, bestIdx = -1;
@@ -1125,6 +1418,16 @@ extern "C" orbx_status orbx_fuse_search(const orbx_keypoint* kps, const uint8_t*
     return ORBX_OK;
 }
 
+extern "C" orbx_status orbx_fuse_search(const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps,
+                                        float min_x, float max_x, float min_y, float max_y, const orbx_query* queries,
+                                        const uint8_t* query_desc, int n_query, const float* inv_level_sigma2,
+                                        int n_levels, int* match_out, int* n_matches) {
+    orbx_frame* F;
+    orbx_status s = scratch_frame(kps, desc, uright, n_kps, min_x, max_x, min_y, max_y, &F);
+    if (s != ORBX_OK) return s;
+    return orbx_frame_fuse_search(F, queries, query_desc, n_query, inv_level_sigma2, n_levels, match_out, n_matches);
+}
+
 extern "C" orbx_status orbx_search_by_sim3(const orbx_keypoint* kps1, const uint8_t* desc1, int n1, const float bounds1[4],
                                            const orbx_keypoint* kps2, const uint8_t* desc2, int n2, const float bounds2[4],
                                            const orbx_query* queries_into2, const uint8_t* query_desc_into2,
@@ -1133,11 +1436,15 @@ extern "C" orbx_status orbx_search_by_sim3(const orbx_keypoint* kps1, const uint
                                            int* matches12, int* n_found) {
     ORBX_REQUIRE(bounds1 && bounds2 && n_found && (n1 == 0 || matches12), "null argument");
     ORBX_REQUIRE((nq1 == 0 || source1) && (nq2 == 0 || source2), "null argument");
-    std::vector<int> vnMatch1(n1, -1), vnMatch2(n2, -1), off, idx, dist;
+    std::vector<int> vnMatch1(n1, -1), vnMatch2(n2, -1);
+    WindowLists L;
+    const int *off, *idx, *dist;
+    orbx_frame* F;
     // KF1's points searched in KF2 (ORBmatcher.cc:1565-1642)
-    orbx_status s = window_candidates_impl(kps2, desc2, nullptr, n2, bounds2[0], bounds2[1], bounds2[2], bounds2[3],
-                                           queries_into2, query_desc_into2, nq1, off, idx, dist);
+    orbx_status s = scratch_frame(kps2, desc2, nullptr, n2, bounds2[0], bounds2[1], bounds2[2], bounds2[3], &F);
+    if (s == ORBX_OK) s = frame_window_lists(*F, queries_into2, query_desc_into2, nq1, L);
     if (s != ORBX_OK) return s;
+    off = L.off; idx = L.idx; dist = L.dist;
     for (int q = 0; q < nq1; ++q) {
         ORBX_REQUIRE(source1[q] >= 0 && source1[q] < n1, "source1[%d] out of range", q);
         int best = 0x7FFFFFFF, bestIdx = -1;
@@ -1146,9 +1453,10 @@ extern "C" orbx_status orbx_search_by_sim3(const orbx_keypoint* kps1, const uint
         if (best <= 100) vnMatch1[source1[q]] = bestIdx;
     }
     // KF2's points searched in KF1 (:1645-1722)
-    s = window_candidates_impl(kps1, desc1, nullptr, n1, bounds1[0], bounds1[1], bounds1[2], bounds1[3], queries_into1,
-                               query_desc_into1, nq2, off, idx, dist);
+    s = scratch_frame(kps1, desc1, nullptr, n1, bounds1[0], bounds1[1], bounds1[2], bounds1[3], &F);
+    if (s == ORBX_OK) s = frame_window_lists(*F, queries_into1, query_desc_into1, nq2, L);
     if (s != ORBX_OK) return s;
+    off = L.off; idx = L.idx; dist = L.dist;
     for (int q = 0; q < nq2; ++q) {
         ORBX_REQUIRE(source2[q] >= 0 && source2[q] < n2, "source2[%d] out of range", q);
         int best = 0x7FFFFFFF, bestIdx = -1;
@@ -1188,10 +1496,12 @@ extern "C" orbx_status orbx_search_for_initialization(const orbx_keypoint* kps1,
         qd.insert(qd.end(), desc1 + 32ll * i1, desc1 + 32ll * i1 + 32);
         src.push_back(i1);
     }
-    std::vector<int> off, idx, dist;
-    orbx_status s = window_candidates_impl(kps2, desc2, nullptr, n2, min_x, max_x, min_y, max_y, qs.data(), qd.data(),
-                                           (int)qs.size(), off, idx, dist);
+    WindowLists L;
+    orbx_frame* F;
+    orbx_status s = scratch_frame(kps2, desc2, nullptr, n2, min_x, max_x, min_y, max_y, &F);
+    if (s == ORBX_OK) s = frame_window_lists(*F, qs.data(), qd.data(), (int)qs.size(), L);
     if (s != ORBX_OK) return s;
+    const int *off = L.off, *idx = L.idx, *dist = L.dist;
     std::vector<int> matchedDistance(n2, 0x7FFFFFFF), matches21(n2, -1);
     RotHist hist(1.0f / kHistoLength);
     int nm = 0;

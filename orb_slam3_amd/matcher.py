@@ -21,6 +21,71 @@ def _desc(a):
     return a
 
 
+class FrameFeatures:
+    """What a Frame / KeyFrame holds for the windowed searches, resident on the device:
+    mvKeysUn, mDescriptors, mvuRight and the 64 x 48 mGrid of Frame::AssignFeaturesToGrid
+    (Frame.cc:468-506), which is built on the device.  bounds = (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+
+    def __init__(self, kps=None, desc=None, uright=None, bounds=None):
+        h = C.c_void_p()
+        check(lib().orbx_frame_create(C.byref(h)))
+        self._h = h
+        if kps is not None:
+            self.assign(kps, desc, uright, bounds)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().orbx_frame_destroy(h)
+            except Exception:
+                pass
+
+    def __len__(self):
+        return int(lib().orbx_frame_size(self._h))
+
+    def assign(self, kps, desc, uright, bounds):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = _desc(desc) if len(kps) else np.zeros((0, 32), np.uint8)
+        ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        assert len(desc) == len(kps) and (ur is None or len(ur) == len(kps))
+        check(lib().orbx_frame_assign(self._h, ptr(kps), ptr(desc), ptr(ur), len(kps), *map(float, bounds)))
+        return self
+
+    def assign_device(self, d_kps, d_desc, d_uright, n, bounds):
+        """d_kps: torch uint8/byte tensor of n KP_DTYPE records, d_desc [n, 32] uint8, d_uright float32 [n] or None,
+        all on the current device (for instance one frame's slice of the batched extractor output)."""
+        check(lib().orbx_frame_assign_device(self._h, C.c_void_p(d_kps.data_ptr()), C.c_void_p(d_desc.data_ptr()),
+                                             None if d_uright is None else C.c_void_p(d_uright.data_ptr()), int(n),
+                                             *map(float, bounds)))
+        return self
+
+    def grid(self):
+        """(cell_start[64 * 48 + 1], cell_idx[]) with cell = column * 48 + row."""
+        start = np.zeros(64 * 48 + 1, np.int32)
+        idx = np.zeros(max(len(self), 1), np.int32)
+        n = C.c_int()
+        check(lib().orbx_frame_grid(self._h, ptr(start), ptr(idx), len(idx), C.byref(n)))
+        return start, idx[:n.value].copy()
+
+    def window_candidates(self, queries, query_desc):
+        """GetFeaturesInArea + distance per query: (offset[nq + 1], idx[], dist[])."""
+        queries = np.ascontiguousarray(queries, QUERY_DTYPE)
+        query_desc = _desc(query_desc) if len(queries) else np.zeros((0, 32), np.uint8)
+        off = np.zeros(len(queries) + 1, np.int32)
+        n = C.c_int()
+        cap = max(64 * len(queries), 1)
+        while True:
+            idx = np.zeros(cap, np.int32)
+            dist = np.zeros(cap, np.int32)
+            st = lib().orbx_frame_window_candidates(self._h, ptr(queries), ptr(query_desc), len(queries), ptr(off),
+                                                    ptr(idx), ptr(dist), cap, C.byref(n))
+            if st == 0 or n.value <= cap:
+                check(st)
+                return off, idx[:n.value].copy(), dist[:n.value].copy()
+            cap = n.value
+
+
 class ORBmatcher:
     """ORBmatcher(nnratio = 0.6, checkOri = true)  (ORBmatcher.cc:38)."""
 
@@ -59,6 +124,45 @@ class ORBmatcher:
         check(lib().orbx_search_by_projection(ptr(kps), ptr(desc), ptr(ur), len(kps), *map(float, bounds),
                                               ptr(queries), ptr(query_desc), len(queries), self.mfNNratio,
                                               ptr(taken), ptr(out), C.byref(nm)))
+        return out, nm.value
+
+    # ---- the same searches on a frame whose features are already on the device --------------
+    def SearchByProjectionIn(self, frame: FrameFeatures, queries, query_desc, taken):
+        """SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) (ORBmatcher.cc:42-147) on a FrameFeatures."""
+        queries, query_desc = self._queries(queries, query_desc)
+        assert taken.dtype == np.uint8 and taken.flags.c_contiguous and len(taken) == len(frame)
+        out = np.full(len(queries), -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_frame_search_by_projection(frame._h, ptr(queries), ptr(query_desc), len(queries),
+                                                    self.mfNNratio, ptr(taken), ptr(out), C.byref(nm)))
+        return out, nm.value
+
+    def SearchWindowBestIn(self, frame: FrameFeatures, queries, query_desc, max_dist, taken=None, query_marks=None,
+                           query_angle=None, rot_factor=1.0 / HISTO_LENGTH):
+        """SearchWindowBest on a FrameFeatures."""
+        queries, query_desc = self._queries(queries, query_desc)
+        if taken is not None:
+            assert taken.dtype == np.uint8 and taken.flags.c_contiguous and len(taken) == len(frame)
+        marks = None if query_marks is None else np.ascontiguousarray(query_marks, np.uint8)
+        qa = None
+        if query_angle is not None and self.mbCheckOrientation:
+            qa = np.ascontiguousarray(query_angle, np.float32)
+        out = np.full(len(queries), -1, np.int32)
+        kpm = np.full(len(frame), -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_frame_search_window_best(frame._h, ptr(queries), ptr(query_desc), len(queries), float(max_dist),
+                                                  ptr(taken), ptr(marks), ptr(qa), float(np.float32(rot_factor)),
+                                                  ptr(out), ptr(kpm), C.byref(nm)))
+        return out, kpm, nm.value
+
+    def FuseIn(self, frame: FrameFeatures, queries, query_desc, inv_level_sigma2):
+        """Fuse on a FrameFeatures."""
+        queries, query_desc = self._queries(queries, query_desc)
+        sig = np.ascontiguousarray(inv_level_sigma2, np.float32)
+        out = np.full(len(queries), -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_frame_fuse_search(frame._h, ptr(queries), ptr(query_desc), len(queries), ptr(sig), len(sig),
+                                           ptr(out), C.byref(nm)))
         return out, nm.value
 
     # ---- the other order-dependent searches (flattened inputs, see include/orbx.h) ----------

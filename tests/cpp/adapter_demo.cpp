@@ -48,6 +48,22 @@ int main(int argc, char** argv) {
         const int nInit = matcher.SearchForInitialization(v1, v2, prev, m12, 100);
         std::string pre = argv[5];
         dump(pre + "_m12.bin", m12); dump(pre + "_prev.bin", prev);
+        // the right image's features kept on the device; the left keypoints searched in it twice, as
+        // Tracking searches one frame several times (SearchByProjection with the frame's own grid)
+        orbx::FrameFeatures FR(kR, dR, nullptr, 0.f, (float)W, 0.f, (float)H);
+        std::vector<int> gStart, gIdx;
+        FR.Grid(gStart, gIdx);
+        std::vector<orbx_query> proj(kL.size());
+        const std::vector<float> sf = exL.GetScaleFactors();
+        for (size_t i = 0; i < kL.size(); ++i)
+            proj[i] = orbx_query{kL[i].x, kL[i].y, 0.f, 15.f * sf[kL[i].octave], kL[i].octave - 1, kL[i].octave};
+        std::vector<uint8_t> taken(kR.size(), 0);
+        std::vector<int> sbp1, sbp2;
+        const int nSbp1 = matcher.SearchByProjection(FR, proj, dL, taken, sbp1);
+        const int nSbp2 = matcher.SearchByProjection(FR, proj, dL, taken, sbp2);   // second pass skips what the first took
+        dump(pre + "_gstart.bin", gStart); dump(pre + "_gidx.bin", gIdx);
+        dump(pre + "_sbp1.bin", sbp1); dump(pre + "_sbp2.bin", sbp2);
+        std::printf("nSbp1=%d nSbp2=%d\n", nSbp1, nSbp2);
         dump(pre + "_kL.bin", kL); dump(pre + "_dL.bin", dL); dump(pre + "_kR.bin", kR); dump(pre + "_dR.bin", dR);
         dump(pre + "_uR.bin", uR); dump(pre + "_depth.bin", depth); dump(pre + "_knn.bin", knn);
         dump(pre + "_pyr3.bin", exL.mvImagePyramid.at(3).pixels);

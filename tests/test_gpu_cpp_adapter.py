@@ -50,3 +50,14 @@ def test_cpp_adapter_matches_oracle(oracle, tmp_path):
     assert f"nInit={n}" in out.stdout and n > 10
     assert np.array_equal(rd("_m12.bin", np.int32), m12)
     assert np.array_equal(rd("_prev.bin", np.float32).reshape(-1, 2), prev2)
+    # orbx::FrameFeatures: device-built grid and two successive SearchByProjection passes over it
+    gs, gi = g2.csr()
+    assert np.array_equal(rd("_gstart.bin", np.int32), gs) and np.array_equal(rd("_gidx.bin", np.int32), gi)
+    sf = eL.scale_factors
+    lv = kL["octave"]
+    taken = np.zeros(len(kR), np.uint8)
+    args = (g2, dR, None, kL["x"], kL["y"], np.zeros(len(kL), np.float32), lv, (np.float32(15.0) * sf[lv]).astype(np.float32), dL)
+    o1, taken, n1 = oracle.search_by_projection(*args, taken, 0.9)
+    o2, taken, n2 = oracle.search_by_projection(*args, taken, 0.9)
+    assert f"nSbp1={n1} nSbp2={n2}" in out.stdout and n1 > 10
+    assert np.array_equal(rd("_sbp1.bin", np.int32), o1) and np.array_equal(rd("_sbp2.bin", np.int32), o2)

@@ -41,12 +41,21 @@ q["radius"] = 7 * (1.2 ** lvl); q["min_level"] = lvl - 1; q["max_level"] = lvl
 qd = d[src].copy()
 m = A.ORBmatcher(0.8)
 bounds = (0.0, float(W), 0.0, float(H))
-for name, fn in [("SearchByProjection (800 map points, 1000 keypoints)",
+frame = A.FrameFeatures(k, d, None, bounds)
+taken = np.zeros(len(k), np.uint8)
+for name, fn in [("FrameFeatures.assign (upload + grid on the device)", lambda: frame.assign(k, d, None, bounds)),
+                 ("SearchByProjectionIn (resident frame, 800 map points)",
+                  lambda: (taken.fill(0), m.SearchByProjectionIn(frame, q, qd, taken))),
+                 ("SearchWindowBestIn + rotation check (resident frame)",
+                  lambda: (taken.fill(0), m.SearchWindowBestIn(frame, q, qd, 100.0, taken, None, k["angle"][src]))),
+                 ("SearchByProjection (800 map points, 1000 keypoints)",
                   lambda: m.SearchByProjection(k, d, None, bounds, q, qd, np.zeros(len(k), np.uint8))),
                  ("SearchWindowBest + rotation check", lambda: m.SearchWindowBest(k, d, None, bounds, q, qd, 100.0, np.zeros(len(k), np.uint8), None, k["angle"][src])),
                  ("knn_match2 1000 x 1000", lambda: A.knn_match2(d, d))]:
     fn(); fn()
-    t0 = time.perf_counter()
-    for _ in range(20):
+    ts = []
+    for _ in range(50):
+        t0 = time.perf_counter()
         fn()
-    print(f"{name:55s} {1e3 * (time.perf_counter() - t0) / 20:7.3f} ms per call")
+        ts.append(1e3 * (time.perf_counter() - t0))
+    print(f"{name:55s} median {np.median(ts):7.3f} ms per call (min {min(ts):.3f}, max {max(ts):.3f})")
