@@ -123,6 +123,49 @@ orbx_status orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_image
                                       orbx_keypoint* d_keypoints, uint8_t* d_descriptors, int capacity,
                                       int* d_counts, void* stream);
 
+/* ---- input staging in front of the extractor ---------------------------------------
+ * What the reference does to a camera image before ORBextractor::operator() sees it:
+ *   cv::remap(im, out, M1, M2, cv::INTER_LINEAR)   System.cc:361-362, when Settings asks for
+ *                                                  rectification (maps from initUndistortRectifyMap,
+ *                                                  CV_32FC1, border constant 0), OR
+ *   cv::resize(im, out, newImSize)                 System.cc:367-370 (INTER_LINEAR), OR nothing,
+ * on the image as delivered (1, 3 or 4 interleaved 8-bit channels), followed by
+ *   cvtColor(im, im, COLOR_{RGB|BGR}[A]2GRAY)      Tracking.cc:1595-1618 (mbRGB picks the order).
+ * A stager holds the per-camera constants (the maps converted to cv::remap's fixed-point form,
+ * or the resize taps) on the device; one kernel produces the grey image.  map_x / map_y are
+ * host arrays of dst_width x dst_height floats (row-major) and are only read by
+ * orbx_stager_create.  For ORBX_STAGE_NONE the output size is the source size. */
+enum { ORBX_STAGE_NONE = 0, ORBX_STAGE_REMAP = 1, ORBX_STAGE_RESIZE = 2 };
+typedef struct orbx_stage_params {
+    int src_width, src_height;
+    int channels;           /* 1, 3 or 4                                            */
+    int rgb_order;          /* Tracking::mbRGB: 1 = R first, 0 = B first            */
+    int mode;               /* ORBX_STAGE_*                                         */
+    int dst_width, dst_height;
+    const float* map_x;     /* ORBX_STAGE_REMAP only                                */
+    const float* map_y;
+    int device;
+} orbx_stage_params;
+typedef struct orbx_stager orbx_stager;
+orbx_status orbx_stager_create(const orbx_stage_params* params, orbx_stager** out);
+void orbx_stager_destroy(orbx_stager* stager);
+orbx_status orbx_stager_output_size(const orbx_stager* stager, int* width, int* height);
+/* One host image in, the grey image out (host pointers, strides in bytes; synchronous). */
+orbx_status orbx_stage(orbx_stager* stager, const uint8_t* src, ptrdiff_t src_stride, uint8_t* dst,
+                       ptrdiff_t dst_stride);
+/* n_frames device images in, grey device images out; asynchronous on `stream`. */
+orbx_status orbx_stage_batch_device(orbx_stager* stager, const uint8_t* d_src, int n_frames,
+                                    ptrdiff_t src_row_stride, ptrdiff_t src_frame_stride, uint8_t* d_dst,
+                                    ptrdiff_t dst_row_stride, ptrdiff_t dst_frame_stride, void* stream);
+/* orbx_extract_batch_device on staged input: the stager writes level 0 of the pyramid directly
+ * (no intermediate grey image, no level-0 copy); d_src are the images as delivered.  The
+ * extractor works at the stager's output size. */
+orbx_status orbx_extract_batch_staged_device(orbx_extractor* ex, orbx_stager* stager, const uint8_t* d_src,
+                                             int n_frames, ptrdiff_t src_row_stride, ptrdiff_t src_frame_stride,
+                                             int lap0, int lap1, const orbx_rect* dyn_host, int ndyn,
+                                             orbx_keypoint* d_keypoints, uint8_t* d_descriptors, int capacity,
+                                             int* d_counts, void* stream);
+
 /* After the stream of the last batched device call has been synchronised: ORBX_OK, or
  * ORBX_ERR_CAPACITY when an internal candidate / output buffer overflowed (results of
  * that call are then invalid; the handle has grown its buffers, call again). */

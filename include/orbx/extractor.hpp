@@ -103,6 +103,50 @@ private:
     std::vector<float> sf_, isf_, s2_, is2_;
 };
 
+// Input staging in front of the extractor: cv::remap with the rectification maps or cv::resize to the configured
+// size (System.cc:355-376), then the grey conversion of Tracking::GrabImage* (Tracking.cc:1591-1619), in one
+// kernel.  One instance per camera; the maps are the CV_32FC1 pair of cv::initUndistortRectifyMap.
+class InputStager {
+public:
+    // rectification: mapX / mapY have dstWidth x dstHeight entries
+    InputStager(int srcWidth, int srcHeight, int channels, bool rgb, const float* mapX, const float* mapY, int dstWidth,
+                int dstHeight, int device = 0) {
+        create(srcWidth, srcHeight, channels, rgb, ORBX_STAGE_REMAP, mapX, mapY, dstWidth, dstHeight, device);
+    }
+    // resize to dstWidth x dstHeight
+    InputStager(int srcWidth, int srcHeight, int channels, bool rgb, int dstWidth, int dstHeight, int device = 0) {
+        create(srcWidth, srcHeight, channels, rgb, ORBX_STAGE_RESIZE, nullptr, nullptr, dstWidth, dstHeight, device);
+    }
+    // grey conversion only
+    InputStager(int srcWidth, int srcHeight, int channels, bool rgb, int device = 0) {
+        create(srcWidth, srcHeight, channels, rgb, ORBX_STAGE_NONE, nullptr, nullptr, srcWidth, srcHeight, device);
+    }
+    ~InputStager() { orbx_stager_destroy(h_); }
+    InputStager(const InputStager&) = delete;
+    InputStager& operator=(const InputStager&) = delete;
+
+    int width() const { return w_; }
+    int height() const { return h2_; }
+    // one host image (stride in bytes) -> the packed grey image ORBextractor receives
+    std::vector<uint8_t> operator()(const uint8_t* image, ptrdiff_t stride) const {
+        std::vector<uint8_t> out((size_t)w_ * h2_);
+        check(orbx_stage(h_, image, stride, out.data(), w_));
+        return out;
+    }
+    orbx_stager* handle() const { return h_; }
+
+private:
+    void create(int sw, int sh, int cn, bool rgb, int mode, const float* mx, const float* my, int dw, int dh, int device) {
+        orbx_stage_params p{};
+        p.src_width = sw; p.src_height = sh; p.channels = cn; p.rgb_order = rgb ? 1 : 0; p.mode = mode;
+        p.dst_width = dw; p.dst_height = dh; p.map_x = mx; p.map_y = my; p.device = device;
+        check(orbx_stager_create(&p, &h_));
+        check(orbx_stager_output_size(h_, &w_, &h2_));
+    }
+    orbx_stager* h_ = nullptr;
+    int w_ = 0, h2_ = 0;
+};
+
 }  // namespace orbx
 
 #ifdef ORBX_WITH_OPENCV

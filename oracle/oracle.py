@@ -51,6 +51,10 @@ def lib():
         L.orc_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.orc_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_gaussian7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p]
+        L.orc_resize_linear_cn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc_remap_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_int, C.c_void_p]
         L.orc_fast.restype = C.c_int
         L.orc_fast.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_int]
         L.orc_fast_strength.restype = C.c_int
@@ -179,6 +183,55 @@ def resize_linear(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
     dst = np.zeros((dh, dw), np.uint8)
     lib().orc_resize_linear(_p(src), src.shape[1], src.shape[0], _p(dst), dw, dh)
     return dst
+
+
+def _hwc(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    return img.reshape(img.shape[0], img.shape[1], -1)
+
+
+def cvt_gray(img: np.ndarray, rgb: bool) -> np.ndarray:
+    """cv::cvtColor(img, COLOR_{RGB|BGR}[A]2GRAY) for an H x W x {3,4} uint8 image."""
+    img = _hwc(img)
+    h, w, cn = img.shape
+    dst = np.zeros((h, w), np.uint8)
+    lib().orc_cvt_gray(_p(img), w, h, w * cn, cn, int(rgb), _p(dst))
+    return dst
+
+
+def resize_linear_cn(img: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    """cv::resize(img, Size(dw, dh)) for H x W [x C] uint8."""
+    src = _hwc(img)
+    h, w, cn = src.shape
+    dst = np.zeros((dh, dw, cn), np.uint8)
+    lib().orc_resize_linear_cn(_p(src), w, h, w * cn, cn, _p(dst), dw, dh)
+    return dst if np.ndim(img) == 3 else dst[:, :, 0]
+
+
+def remap_linear(img: np.ndarray, map_x: np.ndarray, map_y: np.ndarray) -> np.ndarray:
+    """cv::remap(img, map_x, map_y, INTER_LINEAR) for H x W [x C] uint8 and float32 maps."""
+    src = _hwc(img)
+    h, w, cn = src.shape
+    mx = np.ascontiguousarray(map_x, np.float32)
+    my = np.ascontiguousarray(map_y, np.float32)
+    dh, dw = mx.shape
+    dst = np.zeros((dh, dw, cn), np.uint8)
+    lib().orc_remap_linear(_p(src), w, h, w * cn, cn, _p(mx), _p(my), dw, dh, _p(dst))
+    return dst if np.ndim(img) == 3 else dst[:, :, 0]
+
+
+def stage(img: np.ndarray, rgb=False, maps=None, size=None) -> np.ndarray:
+    """The image ORBextractor receives: remap OR resize of the delivered image, then grey conversion."""
+    out = img
+    if maps is not None:
+        out = remap_linear(out, maps[0], maps[1])
+    elif size is not None:
+        out = resize_linear_cn(out, size[0], size[1])
+    if np.ndim(out) == 3 and out.shape[2] >= 3:
+        out = cvt_gray(out, rgb)
+    elif np.ndim(out) == 3:
+        out = out[:, :, 0]
+    return np.ascontiguousarray(out)
 
 
 def gaussian7(src: np.ndarray) -> np.ndarray:

@@ -685,6 +685,114 @@ int orc_level_keypoints(void* h, int level, void* kps, int cap) {
     return (int)k.size();
 }
 
+// ---- input staging in front of the extractor ------------------------------------------------
+// What System::TrackStereo / TrackMonocular and Tracking::GrabImage* do to the camera image before
+// ORBextractor sees it (System.cc:355-376, Tracking.cc:1591-1619): cv::remap with the rectification
+// maps OR cv::resize to the configured size, on the image as delivered (1, 3 or 4 channels), then
+// cv::cvtColor to grey.  The OpenCV arithmetic is restated from the 4.x sources from memory
+// (OpenCV is not in this tree): parity unpinned.
+
+// cv::cvtColor(COLOR_{RGB,BGR,RGBA,BGRA}2GRAY), 8U: 15-bit coefficients R 9798, G 19235, B 3735.
+void orc_cvt_gray(const uint8_t* src, int w, int h, long stride, int cn, int rgb, uint8_t* dst) {
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const uint8_t* p = src + (size_t)y * stride + (size_t)x * cn;
+            const int r = rgb ? p[0] : p[2], g = p[1], b = rgb ? p[2] : p[0];
+            dst[(size_t)y * w + x] = (uint8_t)((r * 9798 + g * 19235 + b * 3735 + (1 << 14)) >> 15);
+        }
+}
+
+// cv::resize(src, dst, Size(dw, dh)) (INTER_LINEAR) for 8U with cn interleaved channels; dst is packed.
+// An exact 2 x 2 decimation is routed to the INTER_AREA fast path by cv::resize: (a + b + c + d + 2) >> 2.
+void orc_resize_linear_cn(const uint8_t* src, int sw, int sh, long stride, int cn, uint8_t* dst, int dw, int dh) {
+    if (sw == dw && sh == dh) {
+        for (int y = 0; y < sh; ++y) std::memcpy(dst + (size_t)y * dw * cn, src + (size_t)y * stride, (size_t)dw * cn);
+        return;
+    }
+    if (sw == 2 * dw && sh == 2 * dh) {
+        for (int y = 0; y < dh; ++y)
+            for (int x = 0; x < dw; ++x)
+                for (int c = 0; c < cn; ++c) {
+                    const uint8_t* p = src + (size_t)(2 * y) * stride + (size_t)(2 * x) * cn + c;
+                    dst[((size_t)y * dw + x) * cn + c] = (uint8_t)((p[0] + p[cn] + p[stride] + p[stride + cn] + 2) >> 2);
+                }
+        return;
+    }
+    std::vector<int> xo, yo; std::vector<short> xa, ya;
+    linear_taps(sw, dw, xo, xa);
+    linear_taps(sh, dh, yo, ya);
+    for (int y = 0; y < dh; ++y) {
+        const int sy0 = yo[y], sy1 = std::min(sy0 + 1, sh - 1);
+        const int b0 = ya[2 * y], b1 = ya[2 * y + 1];
+        for (int x = 0; x < dw; ++x) {
+            const int sx0 = xo[x], sx1 = std::min(sx0 + 1, sw - 1);
+            for (int c = 0; c < cn; ++c) {
+                auto S = [&](int yy, int xx) { return (int)src[(size_t)yy * stride + (size_t)xx * cn + c]; };
+                const int r0 = S(sy0, sx0) * xa[2 * x] + S(sy0, sx1) * xa[2 * x + 1];
+                const int r1 = S(sy1, sx0) * xa[2 * x] + S(sy1, sx1) * xa[2 * x + 1];
+                dst[((size_t)y * dw + x) * cn + c] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+            }
+        }
+    }
+}
+
+// cv::remap(src, dst, map_x, map_y, INTER_LINEAR) with CV_32FC1 maps and the default BORDER_CONSTANT (0):
+// coordinates to 5 fractional bits (cvRound(map * 32)), weights from the 32 x 32 table of 15-bit bilinear
+// coefficients built the way initInterTab2D builds it (saturation to short and its sum repair included),
+// result (sum + 2^14) >> 15.  dst is packed dw x dh x cn.
+void orc_remap_linear(const uint8_t* src, int sw, int sh, long stride, int cn, const float* mapx, const float* mapy,
+                      int dw, int dh, uint8_t* dst) {
+    static short tab[32 * 32][4];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i < 32; ++i)
+            for (int j = 0; j < 32; ++j) {
+                const float vy[2] = {1.f - i / 32.f, i / 32.f}, vx[2] = {1.f - j / 32.f, j / 32.f};
+                short* t = tab[i * 32 + j];
+                int isum = 0;
+                for (int k1 = 0; k1 < 2; ++k1)
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        const int v = round_half_even(vy[k1] * vx[k2] * 32768.f);
+                        t[k1 * 2 + k2] = (short)std::max(-32768, std::min(32767, v));
+                        isum += t[k1 * 2 + k2];
+                    }
+                if (isum != 32768) {
+                    // the repair looks at rows / columns ksize/2 .. ksize/2 + 1 of the kernel; for the 2 x 2 kernel
+                    // only its last element lies inside (the others belong to entries not yet written: zero)
+                    const int diff = isum - 32768;
+                    t[3] = (short)(t[3] - diff);
+                }
+            }
+        init = true;
+    }
+    const unsigned width1 = (unsigned)std::max(sw - 1, 0), height1 = (unsigned)std::max(sh - 1, 0);
+    auto sat16 = [](int v) { return std::max(-32768, std::min(32767, v)); };
+    for (int y = 0; y < dh; ++y)
+        for (int x = 0; x < dw; ++x) {
+            const int fx = round_half_even(mapx[(size_t)y * dw + x] * 32.f);
+            const int fy = round_half_even(mapy[(size_t)y * dw + x] * 32.f);
+            const int sx = sat16(fx >> 5), sy = sat16(fy >> 5);
+            const short* w = tab[(fy & 31) * 32 + (fx & 31)];
+            uint8_t* D = dst + ((size_t)y * dw + x) * cn;
+            if ((unsigned)sx < width1 && (unsigned)sy < height1) {
+                const uint8_t* S = src + (size_t)sy * stride + (size_t)sx * cn;
+                for (int c = 0; c < cn; ++c)
+                    D[c] = (uint8_t)((S[c] * w[0] + S[c + cn] * w[1] + S[stride + c] * w[2] + S[stride + cn + c] * w[3] + (1 << 14)) >> 15);
+            } else if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
+                for (int c = 0; c < cn; ++c) D[c] = 0;
+            } else {
+                const bool x0 = sx >= 0 && sx < sw, x1 = sx + 1 >= 0 && sx + 1 < sw;
+                const bool y0 = sy >= 0 && sy < sh, y1 = sy + 1 >= 0 && sy + 1 < sh;
+                for (int c = 0; c < cn; ++c) {
+                    auto S = [&](int yy, int xx) { return (int)src[(size_t)yy * stride + (size_t)xx * cn + c]; };
+                    const int v0 = (x0 && y0) ? S(sy, sx) : 0, v1 = (x1 && y0) ? S(sy, sx + 1) : 0;
+                    const int v2 = (x0 && y1) ? S(sy + 1, sx) : 0, v3 = (x1 && y1) ? S(sy + 1, sx + 1) : 0;
+                    D[c] = (uint8_t)((v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3] + (1 << 14)) >> 15);
+                }
+            }
+        }
+}
+
 // Stand-alone stages.
 void orc_resize_linear(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh) {
     Plane s, d;

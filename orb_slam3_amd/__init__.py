@@ -8,3 +8,4 @@ from .matcher import (FrameFeatures, ORBmatcher, bucket_allpairs, bucket_best, c
                       distinctive_descriptors,
                       fisheye_ratio_matches, knn2_merge_device, knn_match2, knn_match2_device, window_candidates)
 from .vocabulary import Vocabulary, shared_nodes  # noqa: F401,E402
+from .staging import InputStager  # noqa: F401,E402

@@ -67,6 +67,12 @@ PROTOTYPES = {
     "orbx_search_by_bow_keyframes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "orbx_search_for_triangulation": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orbx_release_cached_memory": (None, []),
+    "orbx_stager_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "orbx_stager_destroy": (None, [C.c_void_p]),
+    "orbx_stager_output_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "orbx_stage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_ssize_t, C.c_void_p, C.c_ssize_t]),
+    "orbx_stage_batch_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_void_p, C.c_ssize_t, C.c_ssize_t, C.c_void_p]),
+    "orbx_extract_batch_staged_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "orbx_frame_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "orbx_frame_destroy": (None, [C.c_void_p]),
     "orbx_frame_assign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),

@@ -10,6 +10,10 @@
 
 void orbx_set_error(const char* fmt, ...);
 
+// orbx_stage.hip: enqueue the staging kernel (strides in bytes); used by the extractor to stage into its pyramid.
+orbx_status orbx_stage_enqueue(orbx_stager* s, const uint8_t* d_src, int n_frames, long long srcRow, long long srcFrame,
+                               uint8_t* d_dst, long long dstRow, long long dstFrame, hipStream_t st);
+
 #define ORBX_HIP_TRY(expr)                                                                   \
     do {                                                                                     \
         hipError_t e__ = (expr);                                                             \

@@ -1536,6 +1536,29 @@ extern "C" orbx_status orbx_extract_batch_device(orbx_extractor* ex, const uint8
     return enqueue_batch(ex, n_frames, lap0, lap1, dyn_host, ndyn, d_keypoints, d_descriptors, capacity, d_counts, st);
 }
 
+extern "C" orbx_status orbx_extract_batch_staged_device(orbx_extractor* ex, orbx_stager* stager, const uint8_t* d_src,
+                                                        int n_frames, ptrdiff_t src_row_stride,
+                                                        ptrdiff_t src_frame_stride, int lap0, int lap1,
+                                                        const orbx_rect* dyn_host, int ndyn, orbx_keypoint* d_keypoints,
+                                                        uint8_t* d_descriptors, int capacity, int* d_counts,
+                                                        void* stream) {
+    ORBX_REQUIRE(ex && stager && d_src && d_keypoints && d_descriptors && d_counts, "null argument");
+    ORBX_REQUIRE(n_frames >= 1 && n_frames <= ex->prm.max_batch, "n_frames %d outside [1, %d]", n_frames, ex->prm.max_batch);
+    int width = 0, height = 0;
+    orbx_status s = orbx_stager_output_size(stager, &width, &height);
+    if (s != ORBX_OK) return s;
+    ORBX_HIP_TRY(hipSetDevice(ex->device));
+    s = ensure_geometry(ex, width, height);
+    if (s != ORBX_OK) return s;
+    hipStream_t st = (hipStream_t)stream;
+    mark(ex, st);
+    const OrbxLevelGeo& L0 = ex->geo.lv[0];
+    s = orbx_stage_enqueue(stager, d_src, n_frames, (long long)src_row_stride, (long long)src_frame_stride,
+                           ex->d_pyr + L0.off, L0.pitch, ex->geo.pyrBytes, st);
+    if (s != ORBX_OK) return s;
+    return enqueue_batch(ex, n_frames, lap0, lap1, dyn_host, ndyn, d_keypoints, d_descriptors, capacity, d_counts, st);
+}
+
 extern "C" orbx_status orbx_extract_status(orbx_extractor* ex) {
     ORBX_REQUIRE(ex, "null handle");
     // the caller has synchronised the stream the batch was launched on

@@ -130,6 +130,33 @@ class ORBextractor:
                                                 desc.data_ptr(), cap, counts.data_ptr(), st))
         return kps, desc, counts
 
+    def extract_batch_staged_device(self, stager, d_src, vLappingArea=(0, 0), out=None, stream=None):
+        """extract_batch_device on images as the camera delivers them: d_src is a torch uint8 CUDA tensor
+        [n, H, W] or [n, H, W, C]; `stager` (InputStager) rectifies / resizes / converts to grey straight
+        into level 0 of the pyramid.  The extractor must have been created for the stager's output size."""
+        import torch
+        assert d_src.is_cuda and d_src.dtype == torch.uint8 and d_src.dim() in (3, 4)
+        nf = d_src.shape[0]
+        cn = 1 if d_src.dim() == 3 else d_src.shape[3]
+        assert cn == stager.channels and tuple(d_src.shape[1:3]) == (stager.src_height, stager.src_width)
+        assert d_src.stride(2) == cn and (d_src.dim() == 3 or d_src.stride(3) == 1)
+        cap = self.max_keypoints
+        if out is None:
+            kps = torch.empty((nf, cap, 28), dtype=torch.uint8, device=d_src.device)
+            desc = torch.empty((nf, cap, 32), dtype=torch.uint8, device=d_src.device)
+            counts = torch.empty((nf, 2), dtype=torch.int32, device=d_src.device)
+        else:
+            kps, desc, counts = out
+        st = torch.cuda.current_stream(d_src.device).cuda_stream if stream is None else stream
+        rects = None
+        if self.mvDynamicArea:
+            rects = np.array([tuple(r) for r in self.mvDynamicArea], RECT_DTYPE)
+        check(self._L.orbx_extract_batch_staged_device(self._h, stager.handle, d_src.data_ptr(), nf, d_src.stride(1),
+                                                       d_src.stride(0), int(vLappingArea[0]), int(vLappingArea[1]),
+                                                       ptr(rects), 0 if rects is None else len(rects), kps.data_ptr(),
+                                                       desc.data_ptr(), cap, counts.data_ptr(), st))
+        return kps, desc, counts
+
     def status(self):
         """Raises if the last asynchronous batch overflowed an internal buffer."""
         check(self._L.orbx_extract_status(self._h))

@@ -265,3 +265,38 @@ def matcher_golden_cases():
     obs = noisy_copy(rng, np.repeat(random_descriptors(len(counts), 107), counts, axis=0), 30)
     cases["distinctive"] = dict(desc=obs, off=off)
     return cases
+
+
+def rectify_maps(w: int, h: int, seed: int, out_size=None, strength: float = 1.0):
+    """Float32 (map_x, map_y) of the kind cv::initUndistortRectifyMap(K, D, R, P, size, CV_32FC1) produces for a
+    radial-tangential camera and a small rectifying rotation: for every output pixel the source position.
+    Some positions fall outside the source image (the constant border of cv::remap)."""
+    rng = np.random.default_rng(seed)
+    ow, oh = out_size if out_size is not None else (w, h)
+    fx, fy, cx, cy = 0.61 * w, 0.61 * w, 0.49 * w, 0.52 * h
+    nfx, nfy, ncx, ncy = 0.47 * ow, 0.47 * ow, 0.5 * ow, 0.5 * oh   # wider than the source: the rim maps outside
+    k1, k2, p1, p2 = (np.array([-0.28, 0.07, 2e-4, -1.5e-4]) * strength + rng.normal(0, 1e-3, 4) * strength)
+    ax, ay, az = rng.normal(0, 0.01, 3) * strength
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    Rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+    iR = np.linalg.inv(Rz @ Ry @ Rx)
+    v, u = np.mgrid[0:oh, 0:ow].astype(np.float64)
+    X = np.stack([(u - ncx) / nfx, (v - ncy) / nfy, np.ones_like(u)], -1) @ iR.T
+    x, y = X[..., 0] / X[..., 2], X[..., 1] / X[..., 2]
+    r2 = x * x + y * y
+    kr = 1 + k1 * r2 + k2 * r2 * r2
+    xd = x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    return (fx * xd + cx).astype(np.float32), (fy * yd + cy).astype(np.float32)
+
+
+def color_scene(w: int, h: int, seed: int, channels: int = 3) -> np.ndarray:
+    """An H x W x channels uint8 image whose channels differ (three differently seeded scenes; alpha = 255)."""
+    planes = [scene(w, h, seed + 1000 * c, n_prims=150) for c in range(3)]
+    base = planes[0].astype(np.int32)
+    img = np.stack([np.clip((base + p.astype(np.int32)) // 2 + 10 * c, 0, 255).astype(np.uint8)
+                    for c, p in enumerate(planes)], -1)
+    if channels == 4:
+        img = np.concatenate([img, np.full((h, w, 1), 255, np.uint8)], -1)
+    return np.ascontiguousarray(img)

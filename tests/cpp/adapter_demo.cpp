@@ -61,6 +61,12 @@ int main(int argc, char** argv) {
         std::vector<int> sbp1, sbp2;
         const int nSbp1 = matcher.SearchByProjection(FR, proj, dL, taken, sbp1);
         const int nSbp2 = matcher.SearchByProjection(FR, proj, dL, taken, sbp2);   // second pass skips what the first took
+        // input staging through the C++ layer: the left image shifted by (+2.25, -1.5) pixels with cv::remap arithmetic
+        std::vector<float> mapX((size_t)W * H), mapY((size_t)W * H);
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) { mapX[(size_t)y * W + x] = x + 2.25f; mapY[(size_t)y * W + x] = y - 1.5f; }
+        orbx::InputStager stager(W, H, 1, false, mapX.data(), mapY.data(), W, H);
+        dump(pre + "_staged.bin", stager(L.data(), W));
         dump(pre + "_gstart.bin", gStart); dump(pre + "_gidx.bin", gIdx);
         dump(pre + "_sbp1.bin", sbp1); dump(pre + "_sbp2.bin", sbp2);
         std::printf("nSbp1=%d nSbp2=%d\n", nSbp1, nSbp2);

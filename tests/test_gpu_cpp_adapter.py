@@ -61,3 +61,7 @@ def test_cpp_adapter_matches_oracle(oracle, tmp_path):
     o2, taken, n2 = oracle.search_by_projection(*args, taken, 0.9)
     assert f"nSbp1={n1} nSbp2={n2}" in out.stdout and n1 > 10
     assert np.array_equal(rd("_sbp1.bin", np.int32), o1) and np.array_equal(rd("_sbp2.bin", np.int32), o2)
+    # orbx::InputStager
+    yy, xx = np.mgrid[0:480, 0:752].astype(np.float32)
+    want = oracle.remap_linear(L, xx + np.float32(2.25), yy - np.float32(1.5))
+    assert np.array_equal(rd("_staged.bin", np.uint8).reshape(480, 752), want)
