@@ -254,10 +254,11 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
                                                        OrbxErr* __restrict__ err) {
     // Dynamic LDS: image tile [R][P] (stored from the 4-byte aligned column at or left of the
     // cell so that rows are fetched with dword loads), strength tile [R][P], and the queue of
-    // pixels that survive the quick reject (one ushort per testable pixel).  After the
-    // strengths are known the image tile is reused for the per-pixel keep flags.
+    // pixels that survive the quick reject (one ushort per testable pixel), later compacted in
+    // place to those that are corners.  After the strengths are known the image tile is reused for
+    // the list of corners that survive the non-maximum suppression.
     extern __shared__ __align__(16) unsigned char fast_smem[];
-    __shared__ int s_nQueue, s_nIni, s_nMin;
+    __shared__ int s_nQueue, s_nIni, s_nMin, s_nKeep;
     const int P = kP ? kP : geo->tileP, R = geo->tileR;
     uint8_t* tile = fast_smem;
     uint8_t* strength = tile + P * R;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     const int xa = x0 & ~3, ox = x0 - xa;
     const int rowDwords = (x0 + tw - xa + 3) >> 2;      // <= P / 4
 
-    if (tid == 0) { s_nQueue = 0; s_nIni = 0; s_nMin = 0; }
+    if (tid == 0) { s_nQueue = 0; s_nIni = 0; s_nMin = 0; s_nKeep = 0; }
     const uint8_t* img = pyr + (long long)frame * frameStride + G.off;
     {
         // lane -> (row, dword of the row); kFastThreads / (P / 4) rows per pass
@@ -392,22 +393,44 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     }
     __syncthreads();
     const int nQueue = s_nQueue;
-    // (B) arc strength of the survivors
-    for (int q = tid; q < nQueue; q += kFastThreads) {
-        const int rec = s_queue[q];
-        const int x = rec & 127, y = rec >> 7;
-        const int st = fast_strength_lds(T, P, x, y);
-        S[y * P + x] = (uint8_t)(st > lowTh ? st : 0);
+    const int lane = tid & 63, waveBase = tid & ~63;
+    const unsigned long long lanesBelow = (1ull << lane) - 1ull;
+    // (B) arc strength of the survivors; those above the lower threshold are corners (about one survivor in
+    // five), and the steps that follow visit only those.  Each wave compacts its corners in place, into the
+    // queue slots it has already consumed (its own 64-entry chunks, in order), so no second list is needed.
+    // Whole waves iterate together: the ballots below need every lane of the wave.
+    int nMine = 0;     // corners of this wave so far (wave-uniform)
+    for (int q0 = waveBase; q0 < nQueue; q0 += kFastThreads) {
+        const int q = q0 + lane;
+        int rec = 0;
+        bool corner = false;
+        if (q < nQueue) {
+            rec = s_queue[q];
+            const int x = rec & 127, y = rec >> 7;
+            const int st = fast_strength_lds(T, P, x, y);
+            corner = st > lowTh;
+            if (corner) S[y * P + x] = (uint8_t)st;      // the strength tile was cleared by the tile load
+        }
+        const unsigned long long bal = __ballot(corner);
+        if (corner) {
+            const int j = nMine + __popcll(bal & lanesBelow);           // j-th corner of this wave
+            s_queue[(j >> 6) * kFastThreads + waveBase + (j & 63)] = (unsigned short)rec;
+        }
+        nMine += __popcll(bal);
     }
     __syncthreads();
-    // (C) 3x3 non-maximum suppression at both thresholds; the verdicts go where the image was
-    for (int q = tid; q < nQueue; q += kFastThreads) {
-        const int rec = s_queue[q];
-        const int x = rec & 127, y = rec >> 7;
-        const uint8_t* sp = S + (y - 1) * P + (x - 1);   // top-left of the 3x3 neighbourhood
-        const int st = sp[P + 1];
-        int flags = 0;
-        if (st != 0) {
+    // (C) 3x3 non-maximum suppression of the corners at both thresholds.  The image tile is no longer needed:
+    // it receives the list of corners kept at either threshold, (verdicts << 14) | position.
+    unsigned short* s_keep = reinterpret_cast<unsigned short*>(tile);
+    const int keepCap = (P * R) >> 1;
+    for (int j0 = 0; j0 < nMine; j0 += 64) {
+        const int j = j0 + lane;
+        int rec = 0, flags = 0;
+        if (j < nMine) {
+            rec = s_queue[(j >> 6) * kFastThreads + waveBase + lane];
+            const int x = rec & 127, y = rec >> 7;
+            const uint8_t* sp = S + (y - 1) * P + (x - 1);   // top-left of the 3x3 neighbourhood
+            const int st = sp[P + 1];
             int nb[8];
             nb[0] = sp[0];         nb[1] = sp[1];         nb[2] = sp[2];
             nb[3] = sp[P];                                nb[4] = sp[P + 2];
@@ -421,17 +444,26 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
             }
             flags = (keepI ? 1 : 0) | (keepM ? 2 : 0);
         }
-        T[y * P + x] = (uint8_t)flags;
-        const unsigned long long bI = __ballot(flags & 1), bM = __ballot(flags & 2);
-        if ((tid & 63) == 0) {
+        const unsigned long long bI = __ballot(flags & 1), bM = __ballot(flags & 2), bK = bI | bM;
+        int base = 0;
+        if (lane == 0 && bK) {
             if (bI) atomicAdd(&s_nIni, __popcll(bI));
             if (bM) atomicAdd(&s_nMin, __popcll(bM));
+            base = atomicAdd(&s_nKeep, __popcll(bK));
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (flags) {
+            // two kept corners are never 8-neighbours, so at most a quarter of the tile's pixels arrive here
+            const int pos = base + __popcll(bK & lanesBelow);
+            if (pos < keepCap) s_keep[pos] = (unsigned short)(rec | (flags << 14));
+            else atomicAdd(&err->cand_overflow, 1);
         }
     }
     __syncthreads();
     const bool useIni = s_nIni > 0;
     const int n = useIni ? s_nIni : s_nMin;
     if (n == 0) return;
+    const int nKeep = min(s_nKeep, keepCap);
     const int wantFlag = useIni ? 1 : 2;
     const int useTh = useIni ? iniTh : minTh;
 
@@ -452,10 +484,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
         __syncthreads();
     }
     const int base = reserve ? s_nQueue : 0;
-    for (int q = tid; q < nQueue; q += kFastThreads) {
-        const int rec = s_queue[q];
-        const int lx = rec & 127, ly = rec >> 7;
-        if (!(T[ly * P + lx] & wantFlag)) continue;
+    for (int q = tid; q < nKeep; q += kFastThreads) {
+        const int rec = s_keep[q];
+        if (!((rec >> 14) & wantFlag)) continue;
+        const int lx = rec & 127, ly = (rec >> 7) & 127;
         const int sc = score_at(S[ly * P + lx], useTh);
         float x = __fadd_rn((float)lx, (float)(x0 - kOrbxMinBorder));
         float y = __fadd_rn((float)ly, (float)(y0 - kOrbxMinBorder));
