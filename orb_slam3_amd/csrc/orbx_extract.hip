@@ -1207,6 +1207,11 @@ struct orbx_extractor {
     orbx_keypoint* h_outKps = nullptr;
     uint8_t* h_outDesc = nullptr;
     int* h_counts = nullptr;
+    // The host entry points replay their whole command sequence (upload, every kernel, downloads) as one
+    // HIP graph: a frame is ~20 dependent commands, and launching them one by one costs more than running them.
+    hipGraphExec_t hostGraph = nullptr;
+    struct { int nf, w, h, lap0, lap1; long epoch; } hostGraphKey = {0, 0, 0, 0, 0, -1};
+    long geoEpoch = 0;             // bumped whenever the device buffers or the geometry change
     // optional per-kernel timing (hipEvents on the launch stream)
     bool timing = false;
     std::vector<hipEvent_t> evPool;          // kTimedStages + 1 events per recorded batch
@@ -1277,6 +1282,7 @@ static void free_geo_buffers(orbx_extractor* ex) {
 // Computes the level / cell / quadtree geometry for a w x h image and (re)allocates the
 // device slabs.  Called at creation for the maximum size and again when the size changes.
 static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
+    ++ex->geoEpoch;
     const orbx_params& P = ex->prm;
     OrbxFrameGeo& g = ex->geo;
     memset(&g, 0, sizeof(g));
@@ -1463,7 +1469,9 @@ extern "C" orbx_status orbx_extractor_create(const orbx_params* p, orbx_extracto
 extern "C" void orbx_extractor_destroy(orbx_extractor* ex) {
     if (!ex) return;
     hipSetDevice(ex->device);
-    if (ex->stream) { hipStreamSynchronize(ex->stream); hipStreamDestroy(ex->stream); }
+    if (ex->stream) hipStreamSynchronize(ex->stream);
+    if (ex->hostGraph) hipGraphExecDestroy(ex->hostGraph);
+    if (ex->stream) hipStreamDestroy(ex->stream);
     for (hipEvent_t e : ex->evPool) hipEventDestroy(e);
     free_geo_buffers(ex);
     hipFree(ex->d_geo); hipFree(ex->d_candCount); hipFree(ex->d_kpCount); hipFree(ex->d_err);
@@ -1591,12 +1599,8 @@ extern "C" orbx_status orbx_extract_batch_staged_device(orbx_extractor* ex, orbx
     return enqueue_batch(ex, n_frames, lap0, lap1, dyn_host, ndyn, d_keypoints, d_descriptors, capacity, d_counts, st);
 }
 
-extern "C" orbx_status orbx_extract_status(orbx_extractor* ex) {
-    ORBX_REQUIRE(ex, "null handle");
-    // the caller has synchronised the stream the batch was launched on
-    ORBX_HIP_TRY(hipSetDevice(ex->device));
-    ORBX_HIP_TRY(hipMemcpy(ex->h_err, ex->d_err, sizeof(OrbxErr), hipMemcpyDeviceToHost));
-    const OrbxErr e = *ex->h_err;
+// Acts on an error record that has been read back from the device (clears the device copy if it was set).
+static orbx_status extract_status_from(orbx_extractor* ex, const OrbxErr e) {
     if (e.cand_overflow || e.kp_overflow || e.out_overflow || e.need_cand)
         ORBX_HIP_TRY(hipMemset(ex->d_err, 0, sizeof(OrbxErr)));
     if (e.cand_overflow) {
@@ -1620,6 +1624,14 @@ extern "C" orbx_status orbx_extract_status(orbx_extractor* ex) {
     return ORBX_OK;
 }
 
+extern "C" orbx_status orbx_extract_status(orbx_extractor* ex) {
+    ORBX_REQUIRE(ex, "null handle");
+    // the caller has synchronised the stream the batch was launched on
+    ORBX_HIP_TRY(hipSetDevice(ex->device));
+    ORBX_HIP_TRY(hipMemcpy(ex->h_err, ex->d_err, sizeof(OrbxErr), hipMemcpyDeviceToHost));
+    return extract_status_from(ex, *ex->h_err);
+}
+
 // Host entry points: images are packed into a pinned staging buffer, uploaded with one linear copy,
 // run through the device path, and the result arrays come back with three linear copies into pinned
 // memory.  (Row-pitched copies straight from pageable memory cost milliseconds per image.)
@@ -1638,6 +1650,7 @@ static orbx_status ensure_host_staging(orbx_extractor* ex) {
     ORBX_HIP_TRY(hipHostMalloc((void**)&ex->h_outDesc, B * ex->outCap * 32));
     ORBX_HIP_TRY(hipHostMalloc((void**)&ex->h_counts, B * 2 * sizeof(int)));
     ex->stageInBytes = inBytes;
+    ++ex->geoEpoch;
     return ORBX_OK;
 }
 
@@ -1658,16 +1671,46 @@ static orbx_status extract_host(orbx_extractor* ex, const uint8_t* const* images
         else for (int y = 0; y < height; ++y) memcpy(dst + (size_t)y * width, images[f] + (ptrdiff_t)y * stride, width);
     }
     const size_t B = (size_t)n_frames;
-    for (int attempt = 0; attempt < 8; ++attempt) {
+    // upload, every kernel, the downloads and the error record, in stream order
+    auto enqueue_all = [&]() -> orbx_status {
         ORBX_HIP_TRY(hipMemcpyAsync(ex->d_in, ex->h_in, B * frameBytes, hipMemcpyHostToDevice, ex->stream));
-        s = orbx_extract_batch_device(ex, ex->d_in, n_frames, width, height, width, (ptrdiff_t)frameBytes, lap0, lap1, dyn,
-                                      ndyn, ex->d_outKps, ex->d_outDesc, ex->outCap, ex->d_counts, ex->stream);
-        if (s != ORBX_OK) return s;
+        orbx_status e = orbx_extract_batch_device(ex, ex->d_in, n_frames, width, height, width, (ptrdiff_t)frameBytes, lap0,
+                                                  lap1, dyn, ndyn, ex->d_outKps, ex->d_outDesc, ex->outCap, ex->d_counts,
+                                                  ex->stream);
+        if (e != ORBX_OK) return e;
         ORBX_HIP_TRY(hipMemcpyAsync(ex->h_counts, ex->d_counts, B * 2 * sizeof(int), hipMemcpyDeviceToHost, ex->stream));
         ORBX_HIP_TRY(hipMemcpyAsync(ex->h_outKps, ex->d_outKps, B * ex->outCap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, ex->stream));
         ORBX_HIP_TRY(hipMemcpyAsync(ex->h_outDesc, ex->d_outDesc, B * ex->outCap * 32, hipMemcpyDeviceToHost, ex->stream));
+        ORBX_HIP_TRY(hipMemcpyAsync(ex->h_err, ex->d_err, sizeof(OrbxErr), hipMemcpyDeviceToHost, ex->stream));
+        return ORBX_OK;
+    };
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        // the sequence is fixed by (frames, size, lapping area) and the handle's buffers: capture it once, replay it
+        const bool graphable = ndyn == 0 && !ex->timing;
+        if (graphable) {
+            auto& k = ex->hostGraphKey;
+            const bool hit = ex->hostGraph && k.nf == n_frames && k.w == width && k.h == height && k.lap0 == lap0 &&
+                             k.lap1 == lap1 && k.epoch == ex->geoEpoch;
+            if (!hit) {
+                if (ex->hostGraph) { hipGraphExecDestroy(ex->hostGraph); ex->hostGraph = nullptr; }
+                hipGraph_t graph = nullptr;
+                ORBX_HIP_TRY(hipStreamBeginCapture(ex->stream, hipStreamCaptureModeThreadLocal));
+                s = enqueue_all();
+                const hipError_t ce = hipStreamEndCapture(ex->stream, &graph);
+                if (s != ORBX_OK) { if (graph) hipGraphDestroy(graph); return s; }
+                ORBX_HIP_TRY(ce);
+                const hipError_t ie = hipGraphInstantiate(&ex->hostGraph, graph, nullptr, nullptr, 0);
+                hipGraphDestroy(graph);
+                ORBX_HIP_TRY(ie);
+                k.nf = n_frames; k.w = width; k.h = height; k.lap0 = lap0; k.lap1 = lap1; k.epoch = ex->geoEpoch;
+            }
+            ORBX_HIP_TRY(hipGraphLaunch(ex->hostGraph, ex->stream));
+        } else {
+            s = enqueue_all();
+            if (s != ORBX_OK) return s;
+        }
         ORBX_HIP_TRY(hipStreamSynchronize(ex->stream));
-        s = orbx_extract_status(ex);
+        s = extract_status_from(ex, *ex->h_err);
         if (s == ORBX_ERR_CAPACITY && ex->h_err->cand_overflow) continue;   // regrown: run again
         break;
     }
