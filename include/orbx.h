@@ -200,7 +200,7 @@ orbx_status orbx_debug_level_keypoints(orbx_extractor* ex, int frame, int level,
 /* The sort of DistributeOctTree's careful phase (ORBextractor.cc:805, std::sort over nodes that
  * tie) on its own: n_arrays arrays of 64-bit elements (key = bits 63..24, payload = bits 23..0),
  * array a = elems[offsets[a] .. offsets[a+1]), at most 2048 elements each.  device_sorted receives
- * the result of the one-wave device sort, host_sorted the result of the sequential restatement
+ * the result of the device sort (one workgroup, pending ranges spread over its waves), host_sorted the result of the sequential restatement
  * of libstdc++'s algorithm run on the host; the two must be identical.  Host pointers. */
 orbx_status orbx_debug_wave_sort(const uint64_t* elems, const int* offsets, int n_arrays,
                                  uint64_t* device_sorted, uint64_t* host_sorted);

@@ -592,7 +592,6 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
     int* base = scanv + cap;        // cap: creation sequence base of a split node's children
     int* tmp = base + cap;          // kQtThreads
     __shared__ int s_size, s_done, s_nExp, s_total, s_careful, s_nE, s_bad;
-    __shared__ int s_sortStack[3 * orbx_sort::kStackDepth];
 
     const int n = min(candCount[frame * nl + level], G.candCap);
     const OrbxCand* C = cands + (long long)frame * geo->candTotal + G.candOff;
@@ -663,11 +662,9 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
             for (int p = tid; p < size; p += kQtThreads) base[p] = (cnt[p] > 1) ? scanv[p] : -1;
             __syncthreads();
         } else {
-            // careful pass: sort the expandable record, split from the back until N nodes.
-            // Wave 0 does both; scanv / base / nbox are free at this point and serve as its scratch.
-            if (tid < 64) orbx_sort::wave_sort(sortbuf, s_nE, s_sortStack, scanv, base,
-                                               reinterpret_cast<orbx_sort::elem_t*>(nbox));
-            __syncthreads();
+            // careful pass: sort the expandable record (all waves), split from the back until N nodes
+            // (wave 0).  scanv / base / nbox / ncnt are free at this point and serve as scratch.
+            orbx_sort::block_sort(sortbuf, s_nE, ncnt, scanv, base, reinterpret_cast<orbx_sort::elem_t*>(nbox));
             for (int p = tid; p < size; p += kQtThreads) base[p] = -1;
             __syncthreads();
             if (tid < 64) {
@@ -1861,23 +1858,23 @@ extern "C" orbx_status orbx_debug_level_keypoints(orbx_extractor* ex, int frame,
     return ORBX_OK;
 }
 
-// ---- stage tap: the one-wave sort on its own -------------------------------------------
+// ---- stage tap: the workgroup sort on its own -------------------------------------------
 constexpr int kSortTapMax = 2048;
 
-__global__ __launch_bounds__(64) void k_sort_tap(unsigned long long* __restrict__ data, const int* __restrict__ offsets) {
+__global__ __launch_bounds__(kQtThreads) void k_sort_tap(unsigned long long* __restrict__ data, const int* __restrict__ offsets) {
     extern __shared__ __align__(16) unsigned char st_smem[];
     const int b = blockIdx.x, n = offsets[b + 1] - offsets[b];
     unsigned long long* v = reinterpret_cast<unsigned long long*>(st_smem);
     unsigned long long* out = v + kSortTapMax;
     int* posL = reinterpret_cast<int*>(out + kSortTapMax);
     int* posR = posL + kSortTapMax;
-    __shared__ int s_stack[3 * orbx_sort::kStackDepth];
+    int* segs = posR + kSortTapMax;     // 6 * (kSortTapMax / 17 + 1) ints
     unsigned long long* g = data + offsets[b];
-    for (int i = threadIdx.x; i < n; i += 64) v[i] = g[i];
+    for (int i = threadIdx.x; i < n; i += kQtThreads) v[i] = g[i];
     __syncthreads();
-    orbx_sort::wave_sort(v, n, s_stack, posL, posR, out);
+    orbx_sort::block_sort(v, n, segs, posL, posR, out);
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 64) g[i] = v[i];
+    for (int i = threadIdx.x; i < n; i += kQtThreads) g[i] = v[i];
 }
 
 extern "C" orbx_status orbx_debug_wave_sort(const uint64_t* elems, const int* offsets, int n_arrays,
@@ -1899,7 +1896,7 @@ extern "C" orbx_status orbx_debug_wave_sort(const uint64_t* elems, const int* of
     hipError_t e = hipMemcpy(d_data, elems, total * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_off, offsets, (n_arrays + 1) * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_sort_tap, dim3(n_arrays), dim3(64), kSortTapMax * 24, 0, d_data, d_off);
+        hipLaunchKernelGGL(k_sort_tap, dim3(n_arrays), dim3(kQtThreads), kSortTapMax * 24 + 6 * (kSortTapMax / 17 + 1) * sizeof(int), 0, d_data, d_off);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(device_sorted, d_data, total * 8, hipMemcpyDeviceToHost);

@@ -205,7 +205,7 @@ def test_candidate_buffer_regrows(oracle):
 
 
 def test_wave_sort_equals_sequential_introsort():
-    """The one-wave device sort must return the permutation of the sequential restatement of
+    """The device sort (one workgroup) must return the permutation of the sequential restatement of
     libstdc++'s std::sort (which tests/test_introsort.py pins to std::sort itself), ties included."""
     import ctypes as C
     A = _gpu()

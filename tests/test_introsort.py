@@ -16,7 +16,7 @@ SRC = textwrap.dedent(r'''
     typedef unsigned long long u64;
     static bool cmp(const u64& a, const u64& b) { return orbx_sort::less(a, b); }
 
-    // Scalar statement of the data-parallel formulation the one-wave device sort uses
+    // Scalar statement of the data-parallel formulation the device sort uses
     // (orbx_wavesort.h): every partition swaps all its (L_k, R_k) pairs at once and returns
     // min(L_K, R_{K-1}); the final pass is a stable sort of each leftover range.
     static void par_sort(std::vector<u64>& v) {
