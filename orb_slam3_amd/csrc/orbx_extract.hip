@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
 // split from the back until the list holds N nodes.  The per-node winner is the key with
 // the highest response, the earliest in emission order among equals.
 // ======================================================================================
-constexpr int kQtThreads = 256;
+constexpr int kQtThreads = 512;
 
 struct QtBox { short ulx, uly, brx, bry; };
 
@@ -548,22 +548,29 @@ __device__ __forceinline__ QtBox qt_child_box(const QtBox b, int q) {
 }
 
 // Exclusive scan of v[0..n) (in place) by the whole workgroup; returns the total.
+// Per-thread chunk sums, a shuffle scan inside each wave, then the wave totals (tmp: one int per wave).
 __device__ int qt_block_scan(int* v, int n, int* tmp) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = (n + kQtThreads - 1) / kQtThreads;
-    const int b = tid * chunk, e = min(b + chunk, n);
+    const int b = min(tid * chunk, n), e = min(b + chunk, n);
     int sum = 0;
     for (int i = b; i < e; ++i) sum += v[i];
-    tmp[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < kQtThreads; off <<= 1) {
-        int add = (tid >= off) ? tmp[tid - off] : 0;
-        __syncthreads();
-        tmp[tid] += add;
-        __syncthreads();
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
     }
-    const int total = tmp[kQtThreads - 1];
-    int run = tmp[tid] - sum;
+    if (lane == 63) tmp[wave] = incl;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kQtThreads / 64; ++w) {
+        const int t = tmp[w];
+        before += (w < wave) ? t : 0;
+        total += t;
+    }
+    int run = before + incl - sum;
     for (int i = b; i < e; ++i) { int t = v[i]; v[i] = run; run += t; }
     __syncthreads();
     return total;
