@@ -377,6 +377,24 @@ orbx_status orbx_frame_assign(orbx_frame* frame, const orbx_keypoint* kps, const
 orbx_status orbx_frame_assign_device(orbx_frame* frame, const orbx_keypoint* d_kps, const uint8_t* d_desc,
                                      const float* d_uright, int n_kps, float min_x, float max_x, float min_y,
                                      float max_y);
+/* Frame::UndistortKeyPoints (Frame.cc:882-913) and Frame::ComputeImageBounds (:916-947) in front of the grid, for
+ * a pinhole camera with radial-tangential distortion: cv::undistortPoints(pts, pts, K, D, Mat(), K), i.e. five
+ * iterations of the inverse model in binary64 and re-projection with the same K.  dist = {k1, k2, p1, p2, k3, k4,
+ * k5, k6} (n_dist of them, the rest 0).  As in the reference, dist[0] == 0 means "no distortion": keypoints are
+ * taken as they are and the bounds are the image.  The frame then holds mvKeysUn; orbx_frame_keypoints returns
+ * them together with {mnMinX, mnMaxX, mnMinY, mnMaxY}.  orbx_image_bounds is ComputeImageBounds on its own. */
+typedef struct orbx_camera {
+    float fx, fy, cx, cy;
+    float dist[8];
+    int n_dist;
+} orbx_camera;
+orbx_status orbx_image_bounds(const orbx_camera* cam, int width, int height, float bounds[4]);
+orbx_status orbx_frame_assign_distorted(orbx_frame* frame, const orbx_camera* cam, int width, int height,
+                                        const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n_kps);
+orbx_status orbx_frame_assign_distorted_device(orbx_frame* frame, const orbx_camera* cam, int width, int height,
+                                               const orbx_keypoint* d_kps, const uint8_t* d_desc,
+                                               const float* d_uright, int n_kps);
+orbx_status orbx_frame_keypoints(const orbx_frame* frame, orbx_keypoint* kps_un, int capacity, float bounds[4]);
 int orbx_frame_size(const orbx_frame* frame);
 /* mGrid as CSR (Frame.h:257): cell_start[64 * 48 + 1] with cell = column * 48 + row, cell_idx[]
  * = keypoint indices, capacity entries; *n_in_grid = keypoints inside the cells. */

@@ -30,6 +30,18 @@ public:
         check(orbx_frame_assign(f_, keysUn.data(), descriptors.data(), uRight, (int)keysUn.size(), mnMinX, mnMaxX, mnMinY,
                                 mnMaxY));
     }
+    // Frame::UndistortKeyPoints + ComputeImageBounds + AssignFeaturesToGrid on the device: `keys` are mvKeys of a
+    // pinhole camera with distortion (cam.dist[0] == 0: taken as they are, as the reference does).
+    void AssignDistorted(const orbx_camera& cam, int width, int height, const std::vector<orbx_keypoint>& keys,
+                         const std::vector<uint8_t>& descriptors, const float* uRight) {
+        check(orbx_frame_assign_distorted(f_, &cam, width, height, keys.data(), descriptors.data(), uRight, (int)keys.size()));
+    }
+    // mvKeysUn and {mnMinX, mnMaxX, mnMinY, mnMaxY} as the frame holds them
+    void KeysUn(std::vector<orbx_keypoint>& keysUn, float bounds[4]) const {
+        keysUn.resize(size() > 0 ? size() : 1);
+        check(orbx_frame_keypoints(f_, keysUn.data(), (int)keysUn.size(), bounds));
+        keysUn.resize(size());
+    }
     int size() const { return orbx_frame_size(f_); }
     // mGrid as CSR: cellStart[64 * 48 + 1] (cell = column * 48 + row) and the keypoint indices.
     void Grid(std::vector<int>& cellStart, std::vector<int>& cellIdx) const {

@@ -51,6 +51,8 @@ def lib():
         L.orc_level_keypoints.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.orc_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_gaussian7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_undistort_points.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_image_bounds.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_cvt_gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_void_p]
         L.orc_resize_linear_cn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.orc_remap_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_void_p,
@@ -232,6 +234,25 @@ def stage(img: np.ndarray, rgb=False, maps=None, size=None) -> np.ndarray:
     elif np.ndim(out) == 3:
         out = out[:, :, 0]
     return np.ascontiguousarray(out)
+
+
+def undistort_points(xy, K, D):
+    """cv::undistortPoints(xy, xy, K, D, Mat(), K) for float32 [n, 2] points; K = (fx, fy, cx, cy)."""
+    xy = np.ascontiguousarray(xy, np.float32)
+    K = np.ascontiguousarray(K, np.float32)
+    D = np.ascontiguousarray(D, np.float32)
+    out = np.zeros_like(xy)
+    lib().orc_undistort_points(_p(xy), len(xy), _p(K), _p(D), len(D), _p(out))
+    return out
+
+
+def image_bounds(w, h, K, D):
+    """Frame::ComputeImageBounds: (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    K = np.ascontiguousarray(K, np.float32)
+    D = np.ascontiguousarray(D, np.float32)
+    b = np.zeros(4, np.float32)
+    lib().orc_image_bounds(w, h, _p(K), _p(D), len(D), _p(b))
+    return b
 
 
 def gaussian7(src: np.ndarray) -> np.ndarray:

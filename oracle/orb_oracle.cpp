@@ -793,6 +793,48 @@ void orc_remap_linear(const uint8_t* src, int sw, int sh, long stride, int cn, c
         }
 }
 
+// cv::undistortPoints(pts, pts, K, D, noArray(), K) on CV_32FC2 points, as Frame::UndistortKeyPoints /
+// ComputeImageBounds use it (Frame.cc:901, :932); OpenCV 4.x cvUndistortPointsInternal with the default criteria
+// (5 iterations, no epsilon test), no tilt terms, restated from memory: parity unpinned.
+// K = {fx, fy, cx, cy} as floats, D = k1 k2 p1 p2 [k3 [k4 k5 k6]].
+void orc_undistort_points(const float* xy, int n, const float* K, const float* D, int nD, float* out) {
+    double k[14] = {0};
+    for (int i = 0; i < nD && i < 8; ++i) k[i] = D[i];
+    const double fx = K[0], fy = K[1], cx = K[2], cy = K[3];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double RR[3][3] = {{fx, 0, cx}, {0, fy, cy}, {0, 0, 1}};     // P * R with R = I, P = K
+    for (int i = 0; i < n; ++i) {
+        double x = xy[2 * i], y = xy[2 * i + 1];
+        const double u = x, v = y;
+        x = (x - cx) * ifx;
+        y = (y - cy) * ify;
+        const double x0 = x, y0 = y;
+        for (int j = 0; j < 5; ++j) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+            const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - deltaX) * icdist;
+            y = (y0 - deltaY) * icdist;
+        }
+        const double xx = RR[0][0] * x + RR[0][1] * y + RR[0][2];
+        const double yy = RR[1][0] * x + RR[1][1] * y + RR[1][2];
+        const double ww = 1. / (RR[2][0] * x + RR[2][1] * y + RR[2][2]);
+        out[2 * i] = (float)(xx * ww);
+        out[2 * i + 1] = (float)(yy * ww);
+    }
+}
+// Frame::ComputeImageBounds (Frame.cc:916-947): {mnMinX, mnMaxX, mnMinY, mnMaxY}
+void orc_image_bounds(int w, int h, const float* K, const float* D, int nD, float* b) {
+    if (nD == 0 || D[0] == 0.0f) { b[0] = 0.f; b[1] = (float)w; b[2] = 0.f; b[3] = (float)h; return; }
+    const float c[8] = {0.f, 0.f, (float)w, 0.f, 0.f, (float)h, (float)w, (float)h};
+    float o[8];
+    orc_undistort_points(c, 4, K, D, nD, o);
+    b[0] = std::min(o[0], o[4]); b[1] = std::max(o[2], o[6]);
+    b[2] = std::min(o[1], o[3]); b[3] = std::max(o[5], o[7]);
+}
+
 // Stand-alone stages.
 void orc_resize_linear(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh) {
     Plane s, d;

@@ -4,7 +4,7 @@ reference's ORBextractor / ORBmatcher interfaces.  No CPU fallback: importing th
 kernels' entry points fails if lib/liborbx.so is missing."""
 from ._lib import KP_DTYPE, MATCH2_DTYPE, QUERY_DTYPE, RECT_DTYPE, OrbxError, lib  # noqa: F401
 from .extractor import ORBextractor, keypoints_from_device  # noqa: F401
-from .matcher import (FrameFeatures, ORBmatcher, bucket_allpairs, bucket_best, compute_stereo_matches, compute_stereo_matches_device,  # noqa: F401
+from .matcher import (Camera, FrameFeatures, ORBmatcher, bucket_allpairs, bucket_best, compute_stereo_matches, compute_stereo_matches_device,  # noqa: F401
                       distinctive_descriptors,
                       fisheye_ratio_matches, knn2_merge_device, knn_match2, knn_match2_device, window_candidates)
 from .vocabulary import Vocabulary, shared_nodes  # noqa: F401,E402

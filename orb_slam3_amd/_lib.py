@@ -78,6 +78,10 @@ PROTOTYPES = {
     "orbx_frame_assign": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
     "orbx_frame_assign_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
     "orbx_frame_size": (C.c_int, [C.c_void_p]),
+    "orbx_image_bounds": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "orbx_frame_assign_distorted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "orbx_frame_assign_distorted_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "orbx_frame_keypoints": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "orbx_frame_grid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "orbx_frame_window_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "orbx_frame_search_by_projection": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),

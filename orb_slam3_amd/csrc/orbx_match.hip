@@ -977,6 +977,68 @@ struct orbx_frame {
     std::vector<orbx_keypoint> hostKps;   // what the in-order loops read (level, angle, position)
 };
 
+// cv::undistortPoints(src, dst, K, D, R = I, P = K) for one point, as Frame::UndistortKeyPoints and
+// ComputeImageBounds call it (Frame.cc:901, :932): normalise, five fixed-point iterations of the inverse
+// radial-tangential model in binary64 (k = k1 k2 p1 p2 k3 k4 k5 k6), project with the same K (given as
+// floats, used as doubles), round to float.  Written once for the kernel and the host (the four image corners).
+struct CamD { double fx, fy, cx, cy, k[8]; };
+__host__ __device__ inline void undistort_point(const CamD& c, float uf, float vf, float* ox, float* oy) {
+    const double ifx = 1. / c.fx, ify = 1. / c.fy;
+    const double u = uf, v = vf;
+    double x = (u - c.cx) * ifx, y = (v - c.cy) * ify;
+    const double x0 = x, y0 = y;
+    const double* k = c.k;
+    for (int j = 0; j < 5; ++j) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        if (icdist < 0) { x = (u - c.cx) * ifx; y = (v - c.cy) * ify; break; }
+        const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+        const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = c.fx * x + 0. * y + c.cx, yy = 0. * x + c.fy * y + c.cy;
+    const double ww = 1. / (0. * x + 0. * y + 1.);
+    *ox = (float)(xx * ww);
+    *oy = (float)(yy * ww);
+}
+
+// in == out is allowed (each thread reads its own record before writing it)
+__global__ __launch_bounds__(256) void k_undistort(CamD c, const orbx_keypoint* in, int n, orbx_keypoint* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    orbx_keypoint kp = in[i];
+    undistort_point(c, kp.x, kp.y, &kp.x, &kp.y);
+    out[i] = kp;
+}
+
+namespace {
+orbx_status camera_to_double(const orbx_camera* cam, CamD& c, bool& distorted) {
+    ORBX_REQUIRE(cam, "null camera");
+    ORBX_REQUIRE(cam->n_dist >= 0 && cam->n_dist <= 8, "n_dist %d outside [0, 8]", cam->n_dist);
+    ORBX_REQUIRE(cam->fx != 0.f && cam->fy != 0.f, "zero focal length");
+    c.fx = cam->fx; c.fy = cam->fy; c.cx = cam->cx; c.cy = cam->cy;
+    for (int i = 0; i < 8; ++i) c.k[i] = i < cam->n_dist ? (double)cam->dist[i] : 0.0;
+    distorted = cam->n_dist > 0 && cam->dist[0] != 0.0f;      // the reference's test (Frame.cc:884, :918)
+    return ORBX_OK;
+}
+}  // namespace
+
+extern "C" orbx_status orbx_image_bounds(const orbx_camera* cam, int width, int height, float bounds[4]) {
+    ORBX_REQUIRE(bounds && width > 0 && height > 0, "bad argument");
+    CamD c;
+    bool distorted;
+    orbx_status s = camera_to_double(cam, c, distorted);
+    if (s != ORBX_OK) return s;
+    if (!distorted) { bounds[0] = 0.f; bounds[1] = (float)width; bounds[2] = 0.f; bounds[3] = (float)height; return ORBX_OK; }
+    float x[4], y[4];
+    const float cu[4] = {0.f, (float)width, 0.f, (float)width}, cv[4] = {0.f, 0.f, (float)height, (float)height};
+    for (int i = 0; i < 4; ++i) undistort_point(c, cu[i], cv[i], &x[i], &y[i]);
+    bounds[0] = std::min(x[0], x[2]); bounds[1] = std::max(x[1], x[3]);
+    bounds[2] = std::min(y[0], y[1]); bounds[3] = std::max(y[2], y[3]);
+    return ORBX_OK;
+}
+
 namespace {
 // Candidate lists of one search; they point into the calling thread's arena and stay valid until
 // that thread's next search.
@@ -998,7 +1060,8 @@ orbx_status frame_set_bounds(orbx_frame& F, float min_x, float max_x, float min_
 
 // Uploads (or copies, for device sources) the features and builds the grid.
 orbx_status frame_assign(orbx_frame& F, const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n,
-                         float min_x, float max_x, float min_y, float max_y, bool fromDevice) {
+                         float min_x, float max_x, float min_y, float max_y, bool fromDevice,
+                         const CamD* undistort = nullptr) {
     ORBX_REQUIRE(n >= 0, "negative size");
     ORBX_REQUIRE(n == 0 || (kps && desc), "null argument");
     orbx_status s = frame_set_bounds(F, min_x, max_x, min_y, max_y);
@@ -1018,10 +1081,16 @@ orbx_status frame_assign(orbx_frame& F, const orbx_keypoint* kps, const uint8_t*
         ORBX_HIP_TRY(hipMemcpyAsync(F.kps.p, kps, (size_t)n * sizeof(orbx_keypoint), kind, st));
         ORBX_HIP_TRY(hipMemcpyAsync(F.desc.p, desc, (size_t)n * 32, kind, st));
         if (uright) ORBX_HIP_TRY(hipMemcpyAsync(F.uright.p, uright, (size_t)n * 4, kind, st));
-        if (fromDevice)
+        if (undistort) {
+            // Frame::UndistortKeyPoints: the frame keeps mvKeysUn; the host mirror is read back
+            hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, st, *undistort,
+                               F.kps.as<orbx_keypoint>(), n, F.kps.as<orbx_keypoint>());
+            ORBX_HIP_TRY(hipMemcpyAsync(F.hostKps.data(), F.kps.p, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, st));
+        } else if (fromDevice) {
             ORBX_HIP_TRY(hipMemcpyAsync(F.hostKps.data(), kps, (size_t)n * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, st));
-        else
+        } else {
             memcpy(F.hostKps.data(), kps, (size_t)n * sizeof(orbx_keypoint));
+        }
     }
     hipLaunchKernelGGL(k_assign_grid, dim3(1), dim3(kGridThreads), 0, st, F.kps.as<orbx_keypoint>(), n, F.minX, F.minY,
                        F.invW, F.invH, F.cellStart.as<int>(), F.cellIdx.as<int>());
@@ -1145,6 +1214,40 @@ extern "C" orbx_status orbx_frame_assign_device(orbx_frame* f, const orbx_keypoi
                                                 float max_y) {
     ORBX_REQUIRE(f, "null frame");
     return frame_assign(*f, d_kps, d_desc, d_uright, n, min_x, max_x, min_y, max_y, true);
+}
+
+static orbx_status frame_assign_camera(orbx_frame* f, const orbx_camera* cam, int width, int height,
+                                       const orbx_keypoint* kps, const uint8_t* desc, const float* uright, int n,
+                                       bool fromDevice) {
+    ORBX_REQUIRE(f, "null frame");
+    CamD c;
+    bool distorted;
+    orbx_status s = camera_to_double(cam, c, distorted);
+    if (s != ORBX_OK) return s;
+    float b[4];
+    s = orbx_image_bounds(cam, width, height, b);
+    if (s != ORBX_OK) return s;
+    return frame_assign(*f, kps, desc, uright, n, b[0], b[1], b[2], b[3], fromDevice, distorted ? &c : nullptr);
+}
+
+extern "C" orbx_status orbx_frame_assign_distorted(orbx_frame* f, const orbx_camera* cam, int width, int height,
+                                                   const orbx_keypoint* kps, const uint8_t* desc, const float* uright,
+                                                   int n) {
+    return frame_assign_camera(f, cam, width, height, kps, desc, uright, n, false);
+}
+
+extern "C" orbx_status orbx_frame_assign_distorted_device(orbx_frame* f, const orbx_camera* cam, int width, int height,
+                                                          const orbx_keypoint* d_kps, const uint8_t* d_desc,
+                                                          const float* d_uright, int n) {
+    return frame_assign_camera(f, cam, width, height, d_kps, d_desc, d_uright, n, true);
+}
+
+extern "C" orbx_status orbx_frame_keypoints(const orbx_frame* f, orbx_keypoint* kps_un, int capacity, float bounds[4]) {
+    ORBX_REQUIRE(f, "null frame");
+    ORBX_REQUIRE(f->n <= capacity, "%d keypoints, capacity %d", f->n, capacity);
+    if (f->n > 0) { ORBX_REQUIRE(kps_un, "null argument"); memcpy(kps_un, f->hostKps.data(), (size_t)f->n * sizeof(orbx_keypoint)); }
+    if (bounds) { bounds[0] = f->minX; bounds[1] = f->maxX; bounds[2] = f->minY; bounds[3] = f->maxY; }
+    return ORBX_OK;
 }
 
 extern "C" int orbx_frame_size(const orbx_frame* f) { return f ? f->n : 0; }

@@ -21,6 +21,21 @@ def _desc(a):
     return a
 
 
+class Camera(C.Structure):
+    """Pinhole camera with radial-tangential distortion: K and DistCoef = (k1, k2, p1, p2[, k3[, k4, k5, k6]])."""
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("dist", C.c_float * 8),
+                ("n_dist", C.c_int)]
+
+    def __init__(self, fx, fy, cx, cy, dist=()):
+        super().__init__(fx, fy, cx, cy, (C.c_float * 8)(*[float(d) for d in dist]), len(dist))
+
+    def image_bounds(self, width, height):
+        """Frame::ComputeImageBounds (Frame.cc:916-947)."""
+        b = np.zeros(4, np.float32)
+        check(lib().orbx_image_bounds(C.byref(self), int(width), int(height), ptr(b)))
+        return b
+
+
 class FrameFeatures:
     """What a Frame / KeyFrame holds for the windowed searches, resident on the device:
     mvKeysUn, mDescriptors, mvuRight and the 64 x 48 mGrid of Frame::AssignFeaturesToGrid
@@ -59,6 +74,29 @@ class FrameFeatures:
                                              None if d_uright is None else C.c_void_p(d_uright.data_ptr()), int(n),
                                              *map(float, bounds)))
         return self
+
+    def assign_distorted(self, camera: Camera, width, height, kps, desc, uright=None):
+        """Frame::UndistortKeyPoints + ComputeImageBounds + AssignFeaturesToGrid on the device: kps are mvKeys."""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = _desc(desc) if len(kps) else np.zeros((0, 32), np.uint8)
+        ur = None if uright is None else np.ascontiguousarray(uright, np.float32)
+        check(lib().orbx_frame_assign_distorted(self._h, C.byref(camera), int(width), int(height), ptr(kps), ptr(desc),
+                                                ptr(ur), len(kps)))
+        return self
+
+    def assign_distorted_device(self, camera: Camera, width, height, d_kps, d_desc, d_uright, n):
+        check(lib().orbx_frame_assign_distorted_device(self._h, C.byref(camera), int(width), int(height),
+                                                       C.c_void_p(d_kps.data_ptr()), C.c_void_p(d_desc.data_ptr()),
+                                                       None if d_uright is None else C.c_void_p(d_uright.data_ptr()),
+                                                       int(n)))
+        return self
+
+    def keypoints(self):
+        """(mvKeysUn, (mnMinX, mnMaxX, mnMinY, mnMaxY)) as the frame holds them."""
+        kps = np.zeros(max(len(self), 1), KP_DTYPE)
+        b = np.zeros(4, np.float32)
+        check(lib().orbx_frame_keypoints(self._h, ptr(kps), len(kps), ptr(b)))
+        return kps[:len(self)].copy(), b
 
     def grid(self):
         """(cell_start[64 * 48 + 1], cell_idx[]) with cell = column * 48 + row."""

@@ -178,3 +178,51 @@ def test_frame_from_device_arrays(oracle):
     out, n = m.SearchByProjectionIn(f, q, qdesc, taken)      # the level of the best / second best comes from the host mirror
     out2, n2 = m.SearchByProjection(kps, desc, ur, BOUNDS, q, qdesc, np.zeros(len(kps), np.uint8))
     assert n == n2 and np.array_equal(out, out2)
+
+
+EUROC_K = (458.654, 457.296, 367.215, 248.375)
+EUROC_D = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)
+
+
+@pytest.mark.parametrize("dist", [EUROC_D, EUROC_D + (0.011,), (0.0, 0.0, 0.0, 0.0), (0.12, -0.2, 1e-3, -5e-4, 0.05, 0.01, -0.02, 0.003)])
+def test_frame_from_distorted_keypoints(oracle, dist):
+    """UndistortKeyPoints + ComputeImageBounds + AssignFeaturesToGrid on the device: bit-identical coordinates
+    (binary64 arithmetic in the same order on both sides), bounds and grid."""
+    A = _gpu()
+    rng = np.random.default_rng(51)
+    kps, desc = _clustered(rng, 3000)
+    kps["x"] = np.clip(kps["x"], 0, 751)
+    kps["y"] = np.clip(kps["y"], 0, 479)
+    cam = A.Camera(*EUROC_K, dist)
+    want_xy = oracle.undistort_points(np.stack([kps["x"], kps["y"]], 1), EUROC_K, dist) if dist[0] != 0 else \
+        np.stack([kps["x"], kps["y"]], 1)
+    want_b = oracle.image_bounds(752, 480, EUROC_K, dist)
+    assert np.array_equal(cam.image_bounds(752, 480), want_b)
+    f = A.FrameFeatures().assign_distorted(cam, 752, 480, kps, desc)
+    un, b = f.keypoints()
+    assert np.array_equal(b, want_b)
+    assert np.array_equal(np.stack([un["x"], un["y"]], 1), want_xy)
+    for name in ("size", "angle", "response", "octave", "class_id"):
+        assert np.array_equal(un[name], kps[name])
+    if dist[0] != 0:
+        assert np.abs(want_xy - np.stack([kps["x"], kps["y"]], 1)).max() > 1.0       # the model does move points
+    want_un = kps.copy()
+    want_un["x"], want_un["y"] = want_xy[:, 0], want_xy[:, 1]
+    start_o, idx_o = oracle.Grid(want_un, *map(float, want_b)).csr()
+    start, idx = f.grid()
+    assert np.array_equal(start, start_o) and np.array_equal(idx, idx_o)
+    # searches on the frame use the undistorted keypoints
+    q, lvl, src = synth.projected_queries(rng, want_un, 500, 7.0, 6.0)
+    qdesc = synth.noisy_copy(rng, desc[src], 50)
+    a = f.window_candidates(q, qdesc)
+    ref = A.window_candidates(want_un, desc, None, tuple(map(float, want_b)), q, qdesc)
+    assert all(np.array_equal(x, y) for x, y in zip(a, ref))
+    # device-resident source
+    import torch
+    dk = torch.from_numpy(kps.view(np.uint8).copy()).cuda()
+    dd = torch.from_numpy(desc.copy()).cuda()
+    torch.cuda.synchronize()
+    f2 = A.FrameFeatures().assign_distorted_device(cam, 752, 480, dk, dd, None, len(kps))
+    un2, b2 = f2.keypoints()
+    assert np.array_equal(un2, un) and np.array_equal(b2, b)
+    assert all(np.array_equal(x, y) for x, y in zip(f2.grid(), (start, idx)))

@@ -66,3 +66,28 @@ def test_stage_composition_order(oracle):
     c = oracle.remap_linear(oracle.cvt_gray(img, True), mx, my)      # the other order rounds differently
     assert a.shape == c.shape and not np.array_equal(a, c)
     assert np.array_equal(oracle.stage(img[..., 0].copy()), img[..., 0])
+
+
+def test_undistort_points_known_answers(oracle):
+    K = (458.654, 457.296, 367.215, 248.375)
+    # no distortion coefficients: normalise and re-project = identity up to one float rounding
+    pts = np.array([[0, 0], [367.215, 248.375], [751, 479], [100.5, 300.25]], np.float32)
+    out = oracle.undistort_points(pts, K, (0, 0, 0, 0))
+    assert np.allclose(out, pts, atol=1e-4)
+    # the principal point is a fixed point of any radial-tangential model
+    D = (-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05)
+    pp = np.array([[K[2], K[3]]], np.float32)
+    assert np.allclose(oracle.undistort_points(pp, K, D), pp, atol=1e-4)
+    # forward model applied to the result reproduces the input (5 iterations converge to << 1 px here)
+    out = oracle.undistort_points(pts, K, D).astype(np.float64)
+    x, y = (out[:, 0] - K[2]) / K[0], (out[:, 1] - K[3]) / K[1]
+    r2 = x * x + y * y
+    kr = 1 + D[0] * r2 + D[1] * r2 * r2
+    xd = x * kr + 2 * D[2] * x * y + D[3] * (r2 + 2 * x * x)
+    yd = y * kr + D[2] * (r2 + 2 * y * y) + 2 * D[3] * x * y
+    back = np.stack([xd * K[0] + K[2], yd * K[1] + K[3]], 1)
+    assert np.abs(back - pts).max() < 0.05
+    # barrel distortion (k1 < 0): undistorted corners lie outside the image
+    b = oracle.image_bounds(752, 480, K, D)
+    assert b[0] < 0 and b[1] > 752 and b[2] < 0 and b[3] > 480
+    assert oracle.image_bounds(752, 480, K, (0, 0, 0, 0)).tolist() == [0, 752, 0, 480]
