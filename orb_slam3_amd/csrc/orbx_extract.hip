@@ -885,7 +885,7 @@ __global__ __launch_bounds__(kLayThreads) void k_layout(const OrbxFrameGeo* __re
 //   256 steered comparisons -> 32 bytes
 // ======================================================================================
 constexpr int kDescWaves = 4;
-constexpr int kRawR = 21, kRawW = 43, kRawP = 64;   // raw rows start at a 16-byte aligned column
+constexpr int kRawR = 21, kRawW = 43, kRawP = 48;   // raw rows start at a 4-byte aligned column (at most 3 + 43 bytes)
 constexpr int kBlurR = 18, kBlurW = 37, kBlurP = 40;
 
 __device__ __forceinline__ int reflect101_dev(int p, int n) {
@@ -954,7 +954,7 @@ __device__ __forceinline__ void sincos_f32(float xf, float* s_out, float* c_out)
 
 // Weight bytes of the orientation disc: entry [|v| * 8 + g] = { (u + 15) for the 4 columns
 // u = 4g - 15 .. 4g - 12 that satisfy |u| <= umax[|v|] (else 0), 1 for the same columns (else 0) }.
-struct OrientWeights { uint32_t w[256]; };
+struct alignas(8) OrientWeights { uint32_t w[256]; };
 constexpr OrientWeights make_orient_weights() {
     OrientWeights t{};
     const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};   // ORBextractor.cc:520-535
@@ -979,10 +979,11 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
                                                               orbx_keypoint* __restrict__ outKps,
                                                               uint8_t* __restrict__ outDesc, int capacity,
                                                               const uint8_t* __restrict__ kpLevel) {
-    __shared__ __align__(16) uint8_t s_raw[kDescWaves][kRawW * kRawP];    // raw patch, later the blurred core
+    // Per wave: the raw patch (later the blurred core) and the transposed row sums.  Nothing is shared between the
+    // waves of a workgroup, and the kernel's speed follows the number of resident waves, i.e. this footprint
+    // (5.6 KB per keypoint: 7 workgroups per CU).
+    __shared__ __align__(16) uint8_t s_raw[kDescWaves][kRawW * kRawP + 16];   // + the dword the last row's window may touch
     __shared__ __align__(16) uint16_t s_hor[kDescWaves][40 * 44];     // transposed row sums: 40 columns x 44 rows
-    __shared__ uint2 s_orientW[128];
-    if (threadIdx.x < 128) s_orientW[threadIdx.x] = make_uint2(c_orientW.w[2 * threadIdx.x], c_orientW.w[2 * threadIdx.x + 1]);
 
     // keypoints of one frame read the same few level images: keep a frame on one XCD
     const int logicalBlock = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
@@ -996,8 +997,6 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
         level = kpLevel[ordinal];
         idx = ordinal - geo->lv[level].kpOff;
     }
-    // Waves without a keypoint stay in step (they only skip the work) so that every
-    // wave of the workgroup reaches the barrier below.
     bool active = level >= 0;
     if (active) active = idx < kpCount[frame * nl + level];
     const OrbxLevelGeo& G = geo->lv[active ? level : 0];
@@ -1012,28 +1011,30 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     uint16_t* hor = s_hor[wv];
     uint8_t* blur = rawBase;   // the raw patch is dead once the horizontal pass is done
 
-    // Patch rows cy-21 .. cy+21, columns cx-21 .. cx+21.  Interior keypoints fetch each row as
-    // four aligned 16-byte loads starting at the 16-byte aligned column xa <= cx-21 (ox = offset
-    // of the patch inside the tile row); keypoints whose patch crosses the level edge take the
-    // byte path with REFLECT_101 indices.
+    // Patch rows cy-21 .. cy+21, columns cx-21 .. cx+21.  Interior keypoints fetch each row as three 16-byte
+    // loads starting at the 4-byte aligned column xa <= cx-21 (ox = offset of the patch inside the tile row;
+    // multi-dword global loads need dword alignment only); keypoints whose patch crosses the level edge take
+    // the byte path with REFLECT_101 indices.
+    struct __attribute__((packed, aligned(4))) Chunk16 { uint32_t a, b, c, d; };
     const int px0 = cx - kRawR, py0 = cy - kRawR;
-    const int xa = px0 & ~15;
+    const int xa = px0 & ~3;
     const bool interior = px0 >= 0 && py0 >= 0 && cx + kRawR < G.w && cy + kRawR < G.h && xa + kRawP <= G.pitch;
     const int ox = interior ? px0 - xa : 0;
     if (active) {
         if (interior) {
-            // 43 rows x 4 chunks of 16 bytes = 172 loads: three per lane, issued together
-            uint4 v[3];
+            // 43 rows x 3 chunks of 16 bytes = 129 loads: issued together (the third round is one lane)
+            Chunk16 v[3];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-                const int i = lane + 64 * u, r = i >> 2, d = i & 3;
+                const int i = lane + 64 * u, r = i / 3, d = i - 3 * r;
                 if (i < kRawW * (kRawP / 16))
-                    v[u] = *reinterpret_cast<const uint4*>(img + (long long)(py0 + r) * G.pitch + xa + 16 * d);
+                    v[u] = *reinterpret_cast<const Chunk16*>(img + (long long)(py0 + r) * G.pitch + xa + 16 * d);
             }
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-                const int i = lane + 64 * u, r = i >> 2, d = i & 3;
-                if (i < kRawW * (kRawP / 16)) *reinterpret_cast<uint4*>(rawBase + r * kRawP + 16 * d) = v[u];
+                const int i = lane + 64 * u, r = i / 3, d = i - 3 * r;
+                if (i < kRawW * (kRawP / 16))
+                    *reinterpret_cast<uint4*>(rawBase + r * kRawP + 16 * d) = make_uint4(v[u].a, v[u].b, v[u].c, v[u].d);
             }
         } else {
             for (int i = lane; i < kRawW * kRawW; i += 64) {
@@ -1043,7 +1044,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
             }
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
 
     // ---- orientation: m10 = sum u*I, m01 = sum v*I over the radius-15 disc ----
     // item = (row v, group of 4 columns u0..u0+3, u0 = 4g - 15): the 4 pixels come as one byte
@@ -1056,7 +1057,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
         if (i < 31 * 8) {
             const int row = i >> 3, g = i & 7;
             const int v = row - 15, av = v < 0 ? -v : v;
-            const uint2 w = s_orientW[av * 8 + g];
+            const uint2 w = *reinterpret_cast<const uint2*>(&c_orientW.w[2 * (av * 8 + g)]);   // 1 KB table, cache resident
             const int b0 = ox + (kRawR - 15) + 4 * g;
             const uint32_t* rowp = reinterpret_cast<const uint32_t*>(rawBase + (kRawR + v) * kRawP) + (b0 >> 2);
             const uint32_t px4 = __builtin_amdgcn_alignbyte(rowp[1], rowp[0], b0 & 3);
