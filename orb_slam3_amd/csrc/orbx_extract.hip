@@ -284,20 +284,43 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     if (tid == 0) { s_nQueue = 0; s_nIni = 0; s_nMin = 0; s_nKeep = 0; }
     const uint8_t* img = pyr + (long long)frame * frameStride + G.off;
     {
-        // lane -> (row, dword of the row); kFastThreads / (P / 4) rows per pass
-        const int RD = P >> 2;
-        const int rowsPerPass = kFastThreads / RD;
-        const int row = tid / RD, xd = tid - row * RD;
-        if (row < rowsPerPass && xd < rowDwords) {
-            const uint8_t* src = img + (long long)(y0 + row) * G.pitch + xa + 4 * xd;
-            uint8_t* dstT = tile + row * P + 4 * xd;
-            uint8_t* dstS = strength + row * P + 4 * xd;
-            const long long srcStep = (long long)rowsPerPass * G.pitch;
-            const int dstStep = rowsPerPass * P;
-            for (int y = row; y < th; y += rowsPerPass) {
-                *reinterpret_cast<uint32_t*>(dstT) = *reinterpret_cast<const uint32_t*>(src);
-                *reinterpret_cast<uint32_t*>(dstS) = 0u;
-                src += srcStep; dstT += dstStep; dstS += dstStep;
+        // lane -> (row, 16-byte chunk of the row): the tile pitch is a multiple of 16 when it is the compile-time
+        // one, and a multi-dword global load only needs dword alignment.  Chunks past the cell's columns are
+        // fetched too (inside the level's slab, never used) -- one load and two LDS stores per lane and pass.
+        if ((P & 15) == 0) {
+            const int RC = P >> 4;                                   // chunks per tile row
+            const int rowsPerPass = kFastThreads / RC;
+            const int row = tid / RC, xc = tid - row * RC;
+            struct __attribute__((packed, aligned(4))) Chunk16 { uint32_t a, b, c, d; };
+            if (row < rowsPerPass) {
+                const uint8_t* src = img + (long long)(y0 + row) * G.pitch + xa + 16 * xc;
+                uint8_t* dstT = tile + row * P + 16 * xc;
+                uint8_t* dstS = strength + row * P + 16 * xc;
+                const long long srcStep = (long long)rowsPerPass * G.pitch;
+                const int dstStep = rowsPerPass * P;
+                for (int y = row; y < th; y += rowsPerPass) {
+                    const Chunk16 v = *reinterpret_cast<const Chunk16*>(src);
+                    *reinterpret_cast<uint4*>(dstT) = make_uint4(v.a, v.b, v.c, v.d);
+                    *reinterpret_cast<uint4*>(dstS) = make_uint4(0u, 0u, 0u, 0u);
+                    src += srcStep; dstT += dstStep; dstS += dstStep;
+                }
+            }
+        } else {
+            // lane -> (row, dword of the row); kFastThreads / (P / 4) rows per pass
+            const int RD = P >> 2;
+            const int rowsPerPass = kFastThreads / RD;
+            const int row = tid / RD, xd = tid - row * RD;
+            if (row < rowsPerPass && xd < rowDwords) {
+                const uint8_t* src = img + (long long)(y0 + row) * G.pitch + xa + 4 * xd;
+                uint8_t* dstT = tile + row * P + 4 * xd;
+                uint8_t* dstS = strength + row * P + 4 * xd;
+                const long long srcStep = (long long)rowsPerPass * G.pitch;
+                const int dstStep = rowsPerPass * P;
+                for (int y = row; y < th; y += rowsPerPass) {
+                    *reinterpret_cast<uint32_t*>(dstT) = *reinterpret_cast<const uint32_t*>(src);
+                    *reinterpret_cast<uint32_t*>(dstS) = 0u;
+                    src += srcStep; dstT += dstStep; dstS += dstStep;
+                }
             }
         }
     }
