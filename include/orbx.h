@@ -365,7 +365,9 @@ orbx_status orbx_search_for_initialization(const orbx_keypoint* kps1, const uint
  * "frame" (same arguments, results and order), minus the per-call upload.  The host-array
  * functions above are these, run on a frame that lives for the call.
  * A frame is immutable between assigns and may be searched from several threads at once;
- * assign / destroy need exclusive access.  uright may be NULL (monocular).
+ * assign / destroy need exclusive access.  uright may be NULL (monocular).  The features live on
+ * the device that is current when assign is called; a search makes that device current for the
+ * calling thread.
  * orbx_frame_assign_device takes device pointers (for instance the output of
  * orbx_extract_batch_device and orbx_stereo_match_batch_device for a camera whose keypoints need
  * no undistortion, Frame.cc:884-888) and copies them; it returns when the copy is complete. */

@@ -357,25 +357,6 @@ extern "C" orbx_status orbx_knn2_merge_device(const orbx_match2* d_parts, int n_
     return ORBX_OK;
 }
 
-extern "C" orbx_status orbx_hamming_knn2(const uint8_t* query, int n_query, const uint8_t* train, int64_t n_train,
-                                         orbx_match2* out) {
-    ORBX_REQUIRE(n_query >= 0 && n_train >= 0, "negative size");
-    if (n_query == 0) return ORBX_OK;
-    ORBX_REQUIRE(query && out && (n_train == 0 || train), "null argument");
-    DevBuf dq, dt, dout, dws;
-    const size_t ws = orbx_knn2_workspace_bytes(n_query, n_train);
-    ORBX_HIP_TRY(dq.alloc((size_t)n_query * 32)); ORBX_HIP_TRY(dt.alloc((size_t)n_train * 32));
-    ORBX_HIP_TRY(dout.alloc((size_t)n_query * sizeof(orbx_match2))); ORBX_HIP_TRY(dws.alloc(ws));
-    ORBX_HIP_TRY(hipMemcpy(dq.p, query, (size_t)n_query * 32, hipMemcpyHostToDevice));
-    if (n_train) ORBX_HIP_TRY(hipMemcpy(dt.p, train, (size_t)n_train * 32, hipMemcpyHostToDevice));
-    orbx_status s = orbx_hamming_knn2_device(dq.as<uint8_t>(), n_query, dt.as<uint8_t>(), n_train, 0, dout.as<orbx_match2>(),
-                                             dws.p, ws, nullptr);
-    if (s != ORBX_OK) return s;
-    ORBX_HIP_TRY(hipDeviceSynchronize());
-    ORBX_HIP_TRY(hipMemcpy(out, dout.p, (size_t)n_query * sizeof(orbx_match2), hipMemcpyDeviceToHost));
-    return ORBX_OK;
-}
-
 // ======================================================================================
 // Frame::ComputeStereoMatches: one wave per left keypoint.
 //   (a) best right keypoint on the same row band / neighbouring octave / disparity range
@@ -952,6 +933,7 @@ struct PinnedArena {
     }
 };
 thread_local PinnedArena t_arena;
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 constexpr int kMaxDevices = 16;
 thread_local hipStream_t t_streams[kMaxDevices] = {};
 
@@ -969,7 +951,43 @@ hipError_t thread_stream(hipStream_t* out) {
 }
 }  // namespace
 
+// Host-array brute-force search (Frame::ComputeStereoFishEyeMatches' knnMatch, Frame.cc:1309).  Per-frame sizes
+// (a thousand descriptors a side) go through the calling thread's pinned arena: one staged upload, the two
+// kernels, results written straight to host memory, one synchronisation of the thread's own stream.
+extern "C" orbx_status orbx_hamming_knn2(const uint8_t* query, int n_query, const uint8_t* train, int64_t n_train,
+                                         orbx_match2* out) {
+    ORBX_REQUIRE(n_query >= 0 && n_train >= 0, "negative size");
+    if (n_query == 0) return ORBX_OK;
+    ORBX_REQUIRE(query && out && (n_train == 0 || train), "null argument");
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
+    DevBuf dq, dt, dws;
+    const size_t ws = orbx_knn2_workspace_bytes(n_query, n_train);
+    const size_t qBytes = (size_t)n_query * 32, tBytes = (size_t)n_train * 32, oBytes = (size_t)n_query * sizeof(orbx_match2);
+    ORBX_HIP_TRY(dq.alloc(qBytes)); ORBX_HIP_TRY(dt.alloc(std::max<size_t>(tBytes, 32))); ORBX_HIP_TRY(dws.alloc(ws));
+    const bool staged = qBytes + tBytes + oBytes <= ((size_t)8 << 20);
+    const size_t oT = align256(qBytes), oOut = align256(oT + tBytes);
+    ORBX_HIP_TRY(t_arena.ensure(staged ? oOut + oBytes : align256(oBytes)));
+    orbx_match2* hOut = reinterpret_cast<orbx_match2*>(t_arena.host + (staged ? oOut : 0));
+    orbx_match2* dOut = reinterpret_cast<orbx_match2*>(t_arena.dev + (staged ? oOut : 0));
+    if (staged) {
+        memcpy(t_arena.host, query, qBytes);
+        if (tBytes) memcpy(t_arena.host + oT, train, tBytes);
+        ORBX_HIP_TRY(hipMemcpyAsync(dq.p, t_arena.host, qBytes, hipMemcpyHostToDevice, st));
+        if (tBytes) ORBX_HIP_TRY(hipMemcpyAsync(dt.p, t_arena.host + oT, tBytes, hipMemcpyHostToDevice, st));
+    } else {
+        ORBX_HIP_TRY(hipMemcpyAsync(dq.p, query, qBytes, hipMemcpyHostToDevice, st));
+        ORBX_HIP_TRY(hipMemcpyAsync(dt.p, train, tBytes, hipMemcpyHostToDevice, st));
+    }
+    orbx_status s = orbx_hamming_knn2_device(dq.as<uint8_t>(), n_query, dt.as<uint8_t>(), n_train, 0, dOut, dws.p, ws, st);
+    if (s != ORBX_OK) return s;
+    ORBX_HIP_TRY(hipStreamSynchronize(st));
+    memcpy(out, hOut, oBytes);
+    return ORBX_OK;
+}
+
 struct orbx_frame {
+    int device = -1;       // where the features live; searches switch the calling thread to it
     int n = 0;
     bool hasUright = false;
     float minX = 0, maxX = 0, minY = 0, maxY = 0, invW = 0, invH = 0;
@@ -1069,6 +1087,13 @@ orbx_status frame_assign(orbx_frame& F, const orbx_keypoint* kps, const uint8_t*
     F.n = n;
     F.hasUright = uright != nullptr;
     F.hostKps.resize(n);
+    int dev = 0;
+    ORBX_HIP_TRY(hipGetDevice(&dev));
+    if (F.device >= 0 && F.device != dev) {
+        // the handle moves to the calling thread's device: its old blocks go back to the cache
+        F.kps.release(); F.desc.release(); F.uright.release(); F.cellStart.release(); F.cellIdx.release();
+    }
+    F.device = dev;
     hipStream_t st;
     ORBX_HIP_TRY(thread_stream(&st));
     ORBX_HIP_TRY(F.cellStart.ensure((size_t)(kGridCells + 1) * 4));
@@ -1099,7 +1124,6 @@ orbx_status frame_assign(orbx_frame& F, const orbx_keypoint* kps, const uint8_t*
     return ORBX_OK;
 }
 
-size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // GetFeaturesInArea for every query + the Hamming distance of every returned keypoint.
 orbx_status frame_window_lists(const orbx_frame& F, const orbx_query* queries, const uint8_t* query_desc, int n_query,
@@ -1107,6 +1131,9 @@ orbx_status frame_window_lists(const orbx_frame& F, const orbx_query* queries, c
     ORBX_REQUIRE(n_query >= 0, "negative size");
     if (n_query == 0 || F.n == 0) { L.set_empty(n_query); return ORBX_OK; }
     ORBX_REQUIRE(queries && query_desc, "null argument");
+    int dev = 0;
+    ORBX_HIP_TRY(hipGetDevice(&dev));
+    if (dev != F.device) ORBX_HIP_TRY(hipSetDevice(F.device));
     if (inv_sigma2) {
         ORBX_REQUIRE(n_levels > 0 && n_levels <= 64, "inv_level_sigma2 needs 1..64 levels");
         for (int i = 0; i < F.n; ++i)
