@@ -77,6 +77,62 @@ struct DevBuf {
 };
 }  // namespace
 
+namespace {
+// Host memory the device reads and writes in place (queries in, candidate lists out): a search
+// is three kernel launches and one stream synchronisation, with no copy commands in between.
+// One arena and one stream per host thread; both live until orbx_release_cached_memory().
+struct PinnedArena {
+    char* host = nullptr;
+    char* dev = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        release();
+        size_t want = (size_t)1 << 20;
+        while (want < bytes) want <<= 1;
+        void* h = nullptr;
+        hipError_t e = hipHostMalloc(&h, want, hipHostMallocPortable | hipHostMallocMapped);
+        if (e != hipSuccess) return e;
+        void* d = nullptr;
+        e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) { (void)hipHostFree(h); return e; }
+        host = static_cast<char*>(h); dev = static_cast<char*>(d); cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (host) (void)hipHostFree(host);
+        host = dev = nullptr; cap = 0;
+    }
+};
+thread_local PinnedArena t_arena;
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr int kMaxDevices = 16;
+thread_local hipStream_t t_streams[kMaxDevices] = {};
+
+hipError_t thread_stream(hipStream_t* out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) { *out = nullptr; return hipSuccess; }   // the default stream
+    if (!t_streams[dev]) {
+        e = hipStreamCreateWithFlags(&t_streams[dev], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *out = t_streams[dev];
+    return hipSuccess;
+}
+}  // namespace
+
+namespace {
+// A copy on the calling thread's stream that has completed, as far as the host can tell, when it returns:
+// uploads from pageable memory are staged before the call returns, downloads are waited for.
+hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+    if (e != hipSuccess || kind != hipMemcpyDeviceToHost) return e;
+    return hipStreamSynchronize(st);
+}
+}  // namespace
+
 static void release_thread_staging();   // the pinned arena and the scratch frames of the windowed searches
 
 extern "C" void orbx_release_cached_memory(void) {
@@ -102,16 +158,18 @@ __global__ void k_pair_distance(const uint32_t* __restrict__ a, const uint32_t* 
 }
 
 extern "C" orbx_status orbx_descriptor_distance(const uint8_t* a, const uint8_t* b, int n, int* out) {
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
     ORBX_REQUIRE(n >= 0 && (n == 0 || (a && b && out)), "bad argument");
     if (n == 0) return ORBX_OK;
     DevBuf da, db, dout;
     ORBX_HIP_TRY(da.alloc((size_t)n * 32)); ORBX_HIP_TRY(db.alloc((size_t)n * 32)); ORBX_HIP_TRY(dout.alloc((size_t)n * 4));
-    ORBX_HIP_TRY(hipMemcpy(da.p, a, (size_t)n * 32, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(db.p, b, (size_t)n * 32, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_pair_distance, dim3((n + 255) / 256), dim3(256), 0, 0, da.as<uint32_t>(), db.as<uint32_t>(), n,
+    ORBX_HIP_TRY(copy_sync(da.p, a, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(db.p, b, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_pair_distance, dim3((n + 255) / 256), dim3(256), 0, st, da.as<uint32_t>(), db.as<uint32_t>(), n,
                        dout.as<int>());
     ORBX_HIP_TRY(hipGetLastError());
-    ORBX_HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_TRY(copy_sync(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     return ORBX_OK;
 }
 
@@ -905,51 +963,6 @@ __global__ __launch_bounds__(kGridThreads) void k_exclusive_scan(const int* __re
     if (threadIdx.x == 0) { offA[n] = total; offB[n] = total; }
 }
 
-namespace {
-// Host memory the device reads and writes in place (queries in, candidate lists out): a search
-// is three kernel launches and one stream synchronisation, with no copy commands in between.
-// One arena and one stream per host thread; both live until orbx_release_cached_memory().
-struct PinnedArena {
-    char* host = nullptr;
-    char* dev = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        release();
-        size_t want = (size_t)1 << 20;
-        while (want < bytes) want <<= 1;
-        void* h = nullptr;
-        hipError_t e = hipHostMalloc(&h, want, hipHostMallocPortable | hipHostMallocMapped);
-        if (e != hipSuccess) return e;
-        void* d = nullptr;
-        e = hipHostGetDevicePointer(&d, h, 0);
-        if (e != hipSuccess) { (void)hipHostFree(h); return e; }
-        host = static_cast<char*>(h); dev = static_cast<char*>(d); cap = want;
-        return hipSuccess;
-    }
-    void release() {
-        if (host) (void)hipHostFree(host);
-        host = dev = nullptr; cap = 0;
-    }
-};
-thread_local PinnedArena t_arena;
-size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-constexpr int kMaxDevices = 16;
-thread_local hipStream_t t_streams[kMaxDevices] = {};
-
-hipError_t thread_stream(hipStream_t* out) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= kMaxDevices) { *out = nullptr; return hipSuccess; }   // the default stream
-    if (!t_streams[dev]) {
-        e = hipStreamCreateWithFlags(&t_streams[dev], hipStreamNonBlocking);
-        if (e != hipSuccess) return e;
-    }
-    *out = t_streams[dev];
-    return hipSuccess;
-}
-}  // namespace
 
 // Host-array brute-force search (Frame::ComputeStereoFishEyeMatches' knnMatch, Frame.cc:1309).  Per-frame sizes
 // (a thousand descriptors a side) go through the calling thread's pinned arena: one staged upload, the two
@@ -1281,14 +1294,16 @@ extern "C" int orbx_frame_size(const orbx_frame* f) { return f ? f->n : 0; }
 
 extern "C" orbx_status orbx_frame_grid(const orbx_frame* f, int* cell_start, int* cell_idx, int capacity,
                                        int* n_in_grid) {
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
     ORBX_REQUIRE(f && cell_start && n_in_grid, "null argument");
     ORBX_REQUIRE(f->cellStart.p, "frame has no features yet");
-    ORBX_HIP_TRY(hipMemcpy(cell_start, f->cellStart.p, (size_t)(kGridCells + 1) * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_TRY(copy_sync(cell_start, f->cellStart.p, (size_t)(kGridCells + 1) * 4, hipMemcpyDeviceToHost, st));
     *n_in_grid = cell_start[kGridCells];
     if (*n_in_grid > capacity) { orbx_set_error("%d keypoints in the grid, capacity %d", *n_in_grid, capacity); return ORBX_ERR_CAPACITY; }
     if (*n_in_grid > 0) {
         ORBX_REQUIRE(cell_idx, "null argument");
-        ORBX_HIP_TRY(hipMemcpy(cell_idx, f->cellIdx.p, (size_t)*n_in_grid * 4, hipMemcpyDeviceToHost));
+        ORBX_HIP_TRY(copy_sync(cell_idx, f->cellIdx.p, (size_t)*n_in_grid * 4, hipMemcpyDeviceToHost, st));
     }
     return ORBX_OK;
 }
@@ -1396,6 +1411,8 @@ __global__ __launch_bounds__(256) void k_bucket_best(const uint32_t* __restrict_
 extern "C" orbx_status orbx_bucket_best(const uint8_t* desc1, int n_desc1, const int* idx1, const int* off1,
                                         const uint8_t* desc2, int n_desc2, const int* idx2, const int* off2, int n_buckets,
                                         int* best_idx2, int* best_dist) {
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
     ORBX_REQUIRE(n_buckets >= 0 && n_desc1 >= 0 && n_desc2 >= 0, "negative size");
     if (n_buckets == 0) return ORBX_OK;
     ORBX_REQUIRE(off1 && off2, "null argument");
@@ -1414,18 +1431,18 @@ extern "C" orbx_status orbx_bucket_best(const uint8_t* desc1, int n_desc1, const
     ORBX_HIP_TRY(I1.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(I2.alloc((size_t)n2 * 4));
     ORBX_HIP_TRY(O1.alloc((size_t)(n_buckets + 1) * 4)); ORBX_HIP_TRY(O2.alloc((size_t)(n_buckets + 1) * 4));
     ORBX_HIP_TRY(BO.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(BI.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(BD.alloc((size_t)n1 * 4));
-    ORBX_HIP_TRY(hipMemcpy(D1.p, desc1, (size_t)n_desc1 * 32, hipMemcpyHostToDevice));
-    if (n_desc2) ORBX_HIP_TRY(hipMemcpy(D2.p, desc2, (size_t)n_desc2 * 32, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(I1.p, idx1, (size_t)n1 * 4, hipMemcpyHostToDevice));
-    if (n2) ORBX_HIP_TRY(hipMemcpy(I2.p, idx2, (size_t)n2 * 4, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(O1.p, off1, (size_t)(n_buckets + 1) * 4, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(O2.p, off2, (size_t)(n_buckets + 1) * 4, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(BO.p, bucketOf.data(), (size_t)n1 * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_bucket_best, dim3((n1 + 3) / 4), dim3(256), 0, 0, D1.as<uint32_t>(), I1.as<int>(), O1.as<int>(),
+    ORBX_HIP_TRY(copy_sync(D1.p, desc1, (size_t)n_desc1 * 32, hipMemcpyHostToDevice, st));
+    if (n_desc2) ORBX_HIP_TRY(copy_sync(D2.p, desc2, (size_t)n_desc2 * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(I1.p, idx1, (size_t)n1 * 4, hipMemcpyHostToDevice, st));
+    if (n2) ORBX_HIP_TRY(copy_sync(I2.p, idx2, (size_t)n2 * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(O1.p, off1, (size_t)(n_buckets + 1) * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(O2.p, off2, (size_t)(n_buckets + 1) * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(BO.p, bucketOf.data(), (size_t)n1 * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_bucket_best, dim3((n1 + 3) / 4), dim3(256), 0, st, D1.as<uint32_t>(), I1.as<int>(), O1.as<int>(),
                        D2.as<uint32_t>(), I2.as<int>(), O2.as<int>(), BO.as<int>(), n1, BI.as<int>(), BD.as<int>());
     ORBX_HIP_TRY(hipGetLastError());
-    ORBX_HIP_TRY(hipMemcpy(best_idx2, BI.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
-    ORBX_HIP_TRY(hipMemcpy(best_dist, BD.p, (size_t)n1 * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_TRY(copy_sync(best_idx2, BI.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_TRY(copy_sync(best_dist, BD.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
     return ORBX_OK;
 }
 
@@ -1700,6 +1717,8 @@ struct BucketPairs {
 static orbx_status bucket_allpairs_impl(const uint8_t* desc1, int n_desc1, const int* idx1, const int* off1,
                                         const uint8_t* desc2, int n_desc2, const int* idx2, const int* off2, int n_buckets,
                                         BucketPairs& bp) {
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
     ORBX_REQUIRE(n_buckets >= 0 && n_desc1 >= 0 && n_desc2 >= 0, "negative size");
     bp.bucketOf.clear(); bp.rowStart.assign(1, 0); bp.dist.clear();
     if (n_buckets == 0) return ORBX_OK;
@@ -1729,17 +1748,17 @@ static orbx_status bucket_allpairs_impl(const uint8_t* desc1, int n_desc1, const
     ORBX_HIP_TRY(I1.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(I2.alloc((size_t)n2 * 4));
     ORBX_HIP_TRY(O2.alloc((size_t)(n_buckets + 1) * 4)); ORBX_HIP_TRY(BO.alloc((size_t)n1 * 4));
     ORBX_HIP_TRY(RS.alloc((size_t)(n1 + 1) * 4)); ORBX_HIP_TRY(OUT.alloc((size_t)total * 2));
-    ORBX_HIP_TRY(hipMemcpy(D1.p, desc1, (size_t)n_desc1 * 32, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(D2.p, desc2, (size_t)n_desc2 * 32, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(I1.p, idx1, (size_t)n1 * 4, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(I2.p, idx2, (size_t)n2 * 4, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(O2.p, off2, (size_t)(n_buckets + 1) * 4, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(BO.p, bp.bucketOf.data(), (size_t)n1 * 4, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(RS.p, bp.rowStart.data(), (size_t)(n1 + 1) * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_bucket_allpairs, dim3((n1 + 3) / 4), dim3(256), 0, 0, D1.as<uint32_t>(), I1.as<int>(),
+    ORBX_HIP_TRY(copy_sync(D1.p, desc1, (size_t)n_desc1 * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(D2.p, desc2, (size_t)n_desc2 * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(I1.p, idx1, (size_t)n1 * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(I2.p, idx2, (size_t)n2 * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(O2.p, off2, (size_t)(n_buckets + 1) * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(BO.p, bp.bucketOf.data(), (size_t)n1 * 4, hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(RS.p, bp.rowStart.data(), (size_t)(n1 + 1) * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_bucket_allpairs, dim3((n1 + 3) / 4), dim3(256), 0, st, D1.as<uint32_t>(), I1.as<int>(),
                        D2.as<uint32_t>(), I2.as<int>(), O2.as<int>(), BO.as<int>(), RS.as<int>(), n1, OUT.as<uint16_t>());
     ORBX_HIP_TRY(hipGetLastError());
-    ORBX_HIP_TRY(hipMemcpy(bp.dist.data(), OUT.p, (size_t)total * 2, hipMemcpyDeviceToHost));
+    ORBX_HIP_TRY(copy_sync(bp.dist.data(), OUT.p, (size_t)total * 2, hipMemcpyDeviceToHost, st));
     return ORBX_OK;
 }
 
@@ -2025,20 +2044,22 @@ extern "C" void orbx_vocabulary_destroy(orbx_vocabulary* v) {
 
 extern "C" orbx_status orbx_bow_transform(orbx_vocabulary* voc, const uint8_t* desc, int n, int levelsup, int* word_id,
                                           double* weight, int* node_id) {
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
     ORBX_REQUIRE(voc && n >= 0 && levelsup >= 0, "bad argument");
     if (n == 0) return ORBX_OK;
     ORBX_REQUIRE(desc && word_id && weight && node_id, "null argument");
     ORBX_HIP_TRY(hipSetDevice(voc->device));
     DevBuf dd, dl, dn;
     ORBX_HIP_TRY(dd.alloc((size_t)n * 32)); ORBX_HIP_TRY(dl.alloc((size_t)n * 4)); ORBX_HIP_TRY(dn.alloc((size_t)n * 4));
-    ORBX_HIP_TRY(hipMemcpy(dd.p, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    ORBX_HIP_TRY(copy_sync(dd.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, st));
     const int nidLevel = voc->depth - levelsup;     // <= 0: the feature vector node is the root
-    hipLaunchKernelGGL(k_bow_descend, dim3((n + 3) / 4), dim3(256), 0, 0, voc->d_childOff, voc->d_childIdx, voc->d_desc,
+    hipLaunchKernelGGL(k_bow_descend, dim3((n + 3) / 4), dim3(256), 0, st, voc->d_childOff, voc->d_childIdx, voc->d_desc,
                        dd.as<uint32_t>(), n, nidLevel, dl.as<int>(), dn.as<int>());
     ORBX_HIP_TRY(hipGetLastError());
     std::vector<int> leaf(n);
-    ORBX_HIP_TRY(hipMemcpy(leaf.data(), dl.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    ORBX_HIP_TRY(hipMemcpy(node_id, dn.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_TRY(copy_sync(leaf.data(), dl.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_TRY(copy_sync(node_id, dn.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     for (int i = 0; i < n; ++i) { word_id[i] = voc->wordId[leaf[i]]; weight[i] = voc->weight[leaf[i]]; }
     return ORBX_OK;
 }
@@ -2137,6 +2158,8 @@ __global__ __launch_bounds__(64) void k_distinctive(const uint32_t* __restrict__
 
 extern "C" orbx_status orbx_distinctive_descriptors(const uint8_t* desc, const int* off, int n_points, int* best_idx,
                                                     int* best_median) {
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
     ORBX_REQUIRE(n_points >= 0, "negative size");
     if (n_points == 0) return ORBX_OK;
     ORBX_REQUIRE(off && best_idx && best_median && off[0] == 0, "bad argument");
@@ -2152,14 +2175,14 @@ extern "C" orbx_status orbx_distinctive_descriptors(const uint8_t* desc, const i
     DevBuf dD, dO, dI, dM;
     ORBX_HIP_TRY(dD.alloc((size_t)std::max(total, 1) * 32)); ORBX_HIP_TRY(dO.alloc((size_t)(n_points + 1) * 4));
     ORBX_HIP_TRY(dI.alloc((size_t)n_points * 4)); ORBX_HIP_TRY(dM.alloc((size_t)n_points * 4));
-    if (total) ORBX_HIP_TRY(hipMemcpy(dD.p, desc, (size_t)total * 32, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(dO.p, off, (size_t)(n_points + 1) * 4, hipMemcpyHostToDevice));
+    if (total) ORBX_HIP_TRY(copy_sync(dD.p, desc, (size_t)total * 32, hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(dO.p, off, (size_t)(n_points + 1) * 4, hipMemcpyHostToDevice, st));
     maxN = (maxN + 1) & ~1;
     const size_t lds = (size_t)maxN * 32 + (size_t)64 * maxN * 2;      // <= 61440 bytes at 384 observations
-    hipLaunchKernelGGL(k_distinctive, dim3(n_points), dim3(64), lds, 0, dD.as<uint32_t>(), dO.as<int>(), dI.as<int>(),
+    hipLaunchKernelGGL(k_distinctive, dim3(n_points), dim3(64), lds, st, dD.as<uint32_t>(), dO.as<int>(), dI.as<int>(),
                        dM.as<int>(), maxN);
     ORBX_HIP_TRY(hipGetLastError());
-    ORBX_HIP_TRY(hipMemcpy(best_idx, dI.p, (size_t)n_points * 4, hipMemcpyDeviceToHost));
-    ORBX_HIP_TRY(hipMemcpy(best_median, dM.p, (size_t)n_points * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_TRY(copy_sync(best_idx, dI.p, (size_t)n_points * 4, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_TRY(copy_sync(best_median, dM.p, (size_t)n_points * 4, hipMemcpyDeviceToHost, st));
     return ORBX_OK;
 }
