@@ -309,3 +309,24 @@ def test_matchers_against_committed_golden(golden_dir):
     d = c["distinctive"]
     bi, bm = A.distinctive_descriptors(d["desc"], d["off"])
     assert np.array_equal(bi, g["distinct_idx"]) and np.array_equal(bm, g["distinct_median"])
+
+
+def test_matcher_entry_points_from_concurrent_threads(golden_dir):
+    """Tracking, LocalMapping and LoopClosing call the matchers at the same time: four threads run the golden
+    cases side by side (each entry point works on the calling thread's own stream and staging); every result must
+    equal the committed vector."""
+    import threading
+    errors = []
+
+    def work():
+        try:
+            for _ in range(5):
+                test_matchers_against_committed_golden(golden_dir)
+        except BaseException as e:      # noqa: BLE001 - collected and re-raised in the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work) for _ in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    if errors:
+        raise errors[0]
