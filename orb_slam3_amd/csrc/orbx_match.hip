@@ -756,23 +756,22 @@ extern "C" orbx_status orbx_stereo_match(orbx_extractor* left, orbx_extractor* r
     ORBX_HIP_TRY(cl.alloc(8)); ORBX_HIP_TRY(cr.alloc(8));
     ORBX_HIP_TRY(ur.alloc((size_t)cap * 4)); ORBX_HIP_TRY(dp.alloc((size_t)cap * 4));
     const int cL[2] = {n_left, 0}, cR[2] = {n_right, 0};
-    ORBX_HIP_TRY(hipMemcpy(kl.p, kps_left, (size_t)n_left * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(dl.p, desc_left, (size_t)n_left * 32, hipMemcpyHostToDevice));
+    hipStream_t st = orbx_internal_stream(left);      // uploads, kernels and downloads in one stream
+    ORBX_HIP_TRY(copy_sync(kl.p, kps_left, (size_t)n_left * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(dl.p, desc_left, (size_t)n_left * 32, hipMemcpyHostToDevice, st));
     if (n_right) {
-        ORBX_HIP_TRY(hipMemcpy(kr.p, kps_right, (size_t)n_right * sizeof(orbx_keypoint), hipMemcpyHostToDevice));
-        ORBX_HIP_TRY(hipMemcpy(dr.p, desc_right, (size_t)n_right * 32, hipMemcpyHostToDevice));
+        ORBX_HIP_TRY(copy_sync(kr.p, kps_right, (size_t)n_right * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
+        ORBX_HIP_TRY(copy_sync(dr.p, desc_right, (size_t)n_right * 32, hipMemcpyHostToDevice, st));
     }
-    ORBX_HIP_TRY(hipMemcpy(cl.p, cL, 8, hipMemcpyHostToDevice));
-    ORBX_HIP_TRY(hipMemcpy(cr.p, cR, 8, hipMemcpyHostToDevice));
-    hipStream_t st = orbx_internal_stream(left);
+    ORBX_HIP_TRY(copy_sync(cl.p, cL, 8, hipMemcpyHostToDevice, st));
+    ORBX_HIP_TRY(copy_sync(cr.p, cR, 8, hipMemcpyHostToDevice, st));
     ORBX_HIP_TRY(hipStreamSynchronize(orbx_internal_stream(right)));   // the right pyramid was built on its own stream
     orbx_status s = orbx_stereo_match_batch_device(left, right, 1, kl.as<orbx_keypoint>(), dl.as<uint8_t>(), cl.as<int>(),
                                                    kr.as<orbx_keypoint>(), dr.as<uint8_t>(), cr.as<int>(), cap, mbf, mb,
                                                    ur.as<float>(), dp.as<float>(), st);
     if (s != ORBX_OK) return s;
-    ORBX_HIP_TRY(hipStreamSynchronize(st));
-    ORBX_HIP_TRY(hipMemcpy(u_right, ur.p, (size_t)n_left * 4, hipMemcpyDeviceToHost));
-    ORBX_HIP_TRY(hipMemcpy(depth, dp.p, (size_t)n_left * 4, hipMemcpyDeviceToHost));
+    ORBX_HIP_TRY(copy_sync(u_right, ur.p, (size_t)n_left * 4, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_TRY(copy_sync(depth, dp.p, (size_t)n_left * 4, hipMemcpyDeviceToHost, st));
     return ORBX_OK;
 }
 

@@ -300,3 +300,26 @@ def color_scene(w: int, h: int, seed: int, channels: int = 3) -> np.ndarray:
     if channels == 4:
         img = np.concatenate([img, np.full((h, w, 1), 255, np.uint8)], -1)
     return np.ascontiguousarray(img)
+
+
+def staging_golden_cases():
+    """The seeded inputs of tests/golden/staging.npz (input staging, undistortion, frame grid): name -> arrays.
+    Shared by tools/make_golden.py and the tests that replay them."""
+    w, h = 160, 120
+    c = {}
+    c["color"] = color_scene(w, h, 71, 3)
+    c["grey"] = scene(w, h, 72, n_prims=60)
+    c["maps"] = rectify_maps(w, h, 73)
+    c["maps_small"] = rectify_maps(w, h, 74, (128, 90))
+    c["resize"] = np.array([133, 101])
+    c["half"] = np.array([80, 60])
+    rng = np.random.default_rng(75)
+    kps, desc = matcher_frame(rng, 1500, None, 30)
+    kps["x"][:300] = rng.normal(300, 6, 300).astype(np.float32)
+    kps["y"][:300] = rng.normal(200, 6, 300).astype(np.float32)
+    kps["x"] = np.clip(kps["x"], 0, 751)
+    kps["y"] = np.clip(kps["y"], 0, 479)
+    c["kps"] = kps
+    c["K"] = np.array([458.654, 457.296, 367.215, 248.375], np.float32)
+    c["D"] = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], np.float32)
+    return c

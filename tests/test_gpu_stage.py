@@ -98,3 +98,25 @@ def test_staged_extraction_equals_extraction_of_staged_image(oracle, mode):
         for f in ("x", "y", "size", "angle", "response", "octave"):
             assert np.array_equal(k[f], k_o[f]), f
         assert np.array_equal(desc[i, :len(k_o)].cpu().numpy(), d_o)
+
+
+def test_staging_against_committed_golden(golden_dir):
+    """The HIP path on the seeded cases of synth.staging_golden_cases() against tests/golden/staging.npz."""
+    import os
+    A = _gpu()
+    g = np.load(os.path.join(golden_dir, "staging.npz"))
+    c = synth.staging_golden_cases()
+    w, h = c["grey"].shape[1], c["grey"].shape[0]
+    assert np.array_equal(A.InputStager(w, h, 3, False, maps=c["maps"])(c["color"]), g["remap_bgr"])
+    assert np.array_equal(A.InputStager(w, h, 3, True, maps=c["maps_small"])(c["color"]), g["remap_rgb_small"])
+    assert np.array_equal(A.InputStager(w, h, 1, False, maps=c["maps"])(c["grey"]), g["remap_grey"])
+    assert np.array_equal(A.InputStager(w, h, 3, False, size=tuple(c["resize"]))(c["color"]), g["resize_bgr"])
+    assert np.array_equal(A.InputStager(w, h, 1, False, size=tuple(c["half"]))(c["grey"]), g["half_grey"])
+    assert np.array_equal(A.InputStager(w, h, 3, True)(c["color"]), g["grey_rgb"])
+    kps = c["kps"]
+    cam = A.Camera(*map(float, c["K"]), tuple(map(float, c["D"])))
+    f = A.FrameFeatures().assign_distorted(cam, 752, 480, kps, synth.random_descriptors(len(kps), 1))
+    un, b = f.keypoints()
+    assert np.array_equal(np.stack([un["x"], un["y"]], 1), g["undistorted"]) and np.array_equal(b, g["bounds"])
+    start, idx = f.grid()
+    assert np.array_equal(start, g["cell_start"]) and np.array_equal(idx, g["cell_idx"])

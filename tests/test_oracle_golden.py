@@ -96,3 +96,22 @@ def test_matchers_golden(oracle, golden_dir):
     for k in g.files:
         assert np.array_equal(np.asarray(now[k]), g[k]), k
     assert int(g["window_n"]) > 100 and int(g["bow_kf_n"]) > 10 and len(np.unique(g["voc_word"])) > 50
+
+
+def _make_golden(golden_dir):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(golden_dir), "..", "tools",
+                                                                              "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return mg
+
+
+def test_staging_golden(oracle, golden_dir):
+    """Input staging, undistortion, bounds and grid of the oracle against tests/golden/staging.npz."""
+    g = np.load(os.path.join(golden_dir, "staging.npz"))
+    out = _make_golden(golden_dir).staging_outputs(oracle)
+    assert sorted(out) == sorted(g.files)
+    for k in out:
+        assert np.array_equal(out[k], g[k]), k
+    assert (g["remap_bgr"] == 0).mean() > 0.02 and g["bounds"][0] < 0 and g["bounds"][1] > 752   # border pixels; barrel distortion

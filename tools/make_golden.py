@@ -55,6 +55,27 @@ def main():
     print("stereo matches", int((uR >= 0).sum()), "of", len(kL))
     # the order-dependent matcher loops, the vocabulary descent and the distinctive-descriptor choice
     np.savez_compressed(os.path.join(OUT, "matchers.npz"), **matcher_outputs(O))
+    # input staging (remap / resize / grey), keypoint undistortion, image bounds and the 64 x 48 grid
+    np.savez_compressed(os.path.join(OUT, "staging.npz"), **staging_outputs(O))
+
+
+def staging_outputs(O):
+    c = synth.staging_golden_cases()
+    out = {}
+    out["remap_bgr"] = O.stage(c["color"], rgb=False, maps=c["maps"])
+    out["remap_rgb_small"] = O.stage(c["color"], rgb=True, maps=c["maps_small"])
+    out["remap_grey"] = O.stage(c["grey"], maps=c["maps"])
+    out["resize_bgr"] = O.stage(c["color"], rgb=False, size=tuple(c["resize"]))
+    out["half_grey"] = O.stage(c["grey"], size=tuple(c["half"]))
+    out["grey_rgb"] = O.stage(c["color"], rgb=True)
+    kps = c["kps"]
+    xy = O.undistort_points(np.stack([kps["x"], kps["y"]], 1), c["K"], c["D"])
+    b = O.image_bounds(752, 480, c["K"], c["D"])
+    un = kps.copy()
+    un["x"], un["y"] = xy[:, 0], xy[:, 1]
+    start, idx = O.Grid(un, *map(float, b)).csr()
+    out.update(undistorted=xy, bounds=b, cell_start=start, cell_idx=idx)
+    return out
 
 
 def matcher_outputs(O):
