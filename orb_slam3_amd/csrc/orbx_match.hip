@@ -158,10 +158,10 @@ __global__ void k_pair_distance(const uint32_t* __restrict__ a, const uint32_t* 
 }
 
 extern "C" orbx_status orbx_descriptor_distance(const uint8_t* a, const uint8_t* b, int n, int* out) {
-    hipStream_t st;
-    ORBX_HIP_TRY(thread_stream(&st));
     ORBX_REQUIRE(n >= 0 && (n == 0 || (a && b && out)), "bad argument");
     if (n == 0) return ORBX_OK;
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
     DevBuf da, db, dout;
     ORBX_HIP_TRY(da.alloc((size_t)n * 32)); ORBX_HIP_TRY(db.alloc((size_t)n * 32)); ORBX_HIP_TRY(dout.alloc((size_t)n * 4));
     ORBX_HIP_TRY(copy_sync(da.p, a, (size_t)n * 32, hipMemcpyHostToDevice, st));
@@ -1293,10 +1293,10 @@ extern "C" int orbx_frame_size(const orbx_frame* f) { return f ? f->n : 0; }
 
 extern "C" orbx_status orbx_frame_grid(const orbx_frame* f, int* cell_start, int* cell_idx, int capacity,
                                        int* n_in_grid) {
-    hipStream_t st;
-    ORBX_HIP_TRY(thread_stream(&st));
     ORBX_REQUIRE(f && cell_start && n_in_grid, "null argument");
     ORBX_REQUIRE(f->cellStart.p, "frame has no features yet");
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
     ORBX_HIP_TRY(copy_sync(cell_start, f->cellStart.p, (size_t)(kGridCells + 1) * 4, hipMemcpyDeviceToHost, st));
     *n_in_grid = cell_start[kGridCells];
     if (*n_in_grid > capacity) { orbx_set_error("%d keypoints in the grid, capacity %d", *n_in_grid, capacity); return ORBX_ERR_CAPACITY; }
@@ -1410,8 +1410,6 @@ __global__ __launch_bounds__(256) void k_bucket_best(const uint32_t* __restrict_
 extern "C" orbx_status orbx_bucket_best(const uint8_t* desc1, int n_desc1, const int* idx1, const int* off1,
                                         const uint8_t* desc2, int n_desc2, const int* idx2, const int* off2, int n_buckets,
                                         int* best_idx2, int* best_dist) {
-    hipStream_t st;
-    ORBX_HIP_TRY(thread_stream(&st));
     ORBX_REQUIRE(n_buckets >= 0 && n_desc1 >= 0 && n_desc2 >= 0, "negative size");
     if (n_buckets == 0) return ORBX_OK;
     ORBX_REQUIRE(off1 && off2, "null argument");
@@ -1425,6 +1423,8 @@ extern "C" orbx_status orbx_bucket_best(const uint8_t* desc1, int n_desc1, const
     }
     for (int i = 0; i < n1; ++i) ORBX_REQUIRE(idx1[i] >= 0 && idx1[i] < n_desc1, "idx1 out of range");
     for (int j = 0; j < n2; ++j) ORBX_REQUIRE(idx2[j] >= 0 && idx2[j] < n_desc2, "idx2 out of range");
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
     DevBuf D1, D2, I1, I2, O1, O2, BO, BI, BD;
     ORBX_HIP_TRY(D1.alloc((size_t)n_desc1 * 32)); ORBX_HIP_TRY(D2.alloc((size_t)n_desc2 * 32));
     ORBX_HIP_TRY(I1.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(I2.alloc((size_t)n2 * 4));
@@ -1716,8 +1716,6 @@ struct BucketPairs {
 static orbx_status bucket_allpairs_impl(const uint8_t* desc1, int n_desc1, const int* idx1, const int* off1,
                                         const uint8_t* desc2, int n_desc2, const int* idx2, const int* off2, int n_buckets,
                                         BucketPairs& bp) {
-    hipStream_t st;
-    ORBX_HIP_TRY(thread_stream(&st));
     ORBX_REQUIRE(n_buckets >= 0 && n_desc1 >= 0 && n_desc2 >= 0, "negative size");
     bp.bucketOf.clear(); bp.rowStart.assign(1, 0); bp.dist.clear();
     if (n_buckets == 0) return ORBX_OK;
@@ -1742,6 +1740,8 @@ static orbx_status bucket_allpairs_impl(const uint8_t* desc1, int n_desc1, const
     ORBX_REQUIRE(desc1 && idx1 && desc2 && idx2, "null argument");
     for (int i = 0; i < n1; ++i) ORBX_REQUIRE(idx1[i] >= 0 && idx1[i] < n_desc1, "idx1 out of range");
     for (int j = 0; j < n2; ++j) ORBX_REQUIRE(idx2[j] >= 0 && idx2[j] < n_desc2, "idx2 out of range");
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
     DevBuf D1, D2, I1, I2, O2, BO, RS, OUT;
     ORBX_HIP_TRY(D1.alloc((size_t)n_desc1 * 32)); ORBX_HIP_TRY(D2.alloc((size_t)n_desc2 * 32));
     ORBX_HIP_TRY(I1.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(I2.alloc((size_t)n2 * 4));
@@ -2043,12 +2043,12 @@ extern "C" void orbx_vocabulary_destroy(orbx_vocabulary* v) {
 
 extern "C" orbx_status orbx_bow_transform(orbx_vocabulary* voc, const uint8_t* desc, int n, int levelsup, int* word_id,
                                           double* weight, int* node_id) {
-    hipStream_t st;
-    ORBX_HIP_TRY(thread_stream(&st));
     ORBX_REQUIRE(voc && n >= 0 && levelsup >= 0, "bad argument");
     if (n == 0) return ORBX_OK;
     ORBX_REQUIRE(desc && word_id && weight && node_id, "null argument");
     ORBX_HIP_TRY(hipSetDevice(voc->device));
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
     DevBuf dd, dl, dn;
     ORBX_HIP_TRY(dd.alloc((size_t)n * 32)); ORBX_HIP_TRY(dl.alloc((size_t)n * 4)); ORBX_HIP_TRY(dn.alloc((size_t)n * 4));
     ORBX_HIP_TRY(copy_sync(dd.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, st));
@@ -2157,8 +2157,6 @@ __global__ __launch_bounds__(64) void k_distinctive(const uint32_t* __restrict__
 
 extern "C" orbx_status orbx_distinctive_descriptors(const uint8_t* desc, const int* off, int n_points, int* best_idx,
                                                     int* best_median) {
-    hipStream_t st;
-    ORBX_HIP_TRY(thread_stream(&st));
     ORBX_REQUIRE(n_points >= 0, "negative size");
     if (n_points == 0) return ORBX_OK;
     ORBX_REQUIRE(off && best_idx && best_median && off[0] == 0, "bad argument");
@@ -2171,6 +2169,8 @@ extern "C" orbx_status orbx_distinctive_descriptors(const uint8_t* desc, const i
     }
     const int total = off[n_points];
     ORBX_REQUIRE(total == 0 || desc, "null descriptors");
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
     DevBuf dD, dO, dI, dM;
     ORBX_HIP_TRY(dD.alloc((size_t)std::max(total, 1) * 32)); ORBX_HIP_TRY(dO.alloc((size_t)(n_points + 1) * 4));
     ORBX_HIP_TRY(dI.alloc((size_t)n_points * 4)); ORBX_HIP_TRY(dM.alloc((size_t)n_points * 4));
