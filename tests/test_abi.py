@@ -71,3 +71,30 @@ def test_argument_validation_without_device():
     out = np.zeros(4, np.int32)
     assert L.orbx_hamming_knn2(None, -1, None, 0, None) == _lib.ORBX_ERR_INVALID
     assert L.orbx_descriptor_distance(None, None, 0, None) == _lib.ORBX_OK
+
+
+def test_new_handles_validate_without_device(oracle):
+    """Stager / frame / camera arguments are checked before any device work; the image bounds are host arithmetic
+    and equal the oracle's ComputeImageBounds."""
+    import orb_slam3_amd as A
+    from orb_slam3_amd import _lib
+    from orb_slam3_amd.staging import StageParams
+    L = _lib.lib()
+    h = C.c_void_p()
+    p = StageParams(752, 480, 2, 0, 0, 0, 0, None, None, 0)
+    assert L.orbx_stager_create(C.byref(p), C.byref(h)) == _lib.ORBX_ERR_INVALID and b"channels" in L.orbx_last_error()
+    p = StageParams(752, 480, 1, 0, 1, 752, 480, None, None, 0)          # remap without maps
+    assert L.orbx_stager_create(C.byref(p), C.byref(h)) == _lib.ORBX_ERR_INVALID and b"maps" in L.orbx_last_error()
+    p = StageParams(752, 480, 1, 0, 2, 0, 480, None, None, 0)            # resize to nothing
+    assert L.orbx_stager_create(C.byref(p), C.byref(h)) == _lib.ORBX_ERR_INVALID
+    p = StageParams(0, 480, 1, 0, 0, 0, 0, None, None, 0)
+    assert L.orbx_stager_create(C.byref(p), C.byref(h)) == _lib.ORBX_ERR_INVALID
+    K = (458.654, 457.296, 367.215, 248.375)
+    for D in [(-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05), (0.0, 0.1, 0.0, 0.0), (),
+              (0.12, -0.2, 1e-3, -5e-4, 0.05)]:
+        assert np.array_equal(A.Camera(*K, D).image_bounds(752, 480), oracle.image_bounds(752, 480, K, D))
+    cam = A.Camera(0.0, 457.0, 367.0, 248.0, (0.1,))
+    b = np.zeros(4, np.float32)
+    assert L.orbx_image_bounds(C.byref(cam), 752, 480, b.ctypes.data_as(C.c_void_p)) == _lib.ORBX_ERR_INVALID
+    assert L.orbx_frame_assign(None, None, None, None, 0, 0.0, 1.0, 0.0, 1.0) == _lib.ORBX_ERR_INVALID
+    assert L.orbx_frame_size(None) == 0
