@@ -80,11 +80,17 @@ struct OrbxErr {
 // ======================================================================================
 constexpr int kResizeRows = 4;   // output rows per lane: taps are fetched once, source rows are reused
 
-// the four left (.x) and right (.y) neighbours of a lane's outputs in source row `row`
-__device__ __forceinline__ uint2 resize_gather(const uint8_t* __restrict__ row, int base, int sh, uint32_t sel0, uint32_t sel1) {
+// the three aligned dwords that hold a lane's 8-byte source window of one row
+struct ResizeRaw { uint32_t d0, d1, d2; };
+__device__ __forceinline__ ResizeRaw resize_load(const uint8_t* __restrict__ row, int base) {
     const uint32_t* p = reinterpret_cast<const uint32_t*>(row + base);
-    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    ResizeRaw r;
+    r.d0 = p[0]; r.d1 = p[1]; r.d2 = p[2];
+    return r;
+}
+// the four left (.x) and right (.y) neighbours of the lane's outputs, cut out of the window
+__device__ __forceinline__ uint2 resize_gather(const ResizeRaw r, int sh, uint32_t sel0, uint32_t sel1) {
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(r.d1, r.d0, sh), w1 = __builtin_amdgcn_alignbyte(r.d2, r.d1, sh);
     return make_uint2(__builtin_amdgcn_perm(w1, w0, sel0), __builtin_amdgcn_perm(w1, w0, sel1));
 }
 
@@ -118,42 +124,63 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__
     }
     const int base = o.x & ~3, sh = o.x & 3;
 
-    // the gathered bytes of the previous lower source row are kept: consecutive output rows
-    // usually continue from it (sy0 of this row == sy1 of the previous one)
-    int heldRow = -1;
-    uint2 held = make_uint2(0u, 0u);
+    // Vertical taps of the lane's rows (wave-uniform), then every source row the rows need is requested before
+    // any of them is used: the kernel's time is the memory latency, so the loads of all rows are in flight
+    // together.  A row whose upper source row is the previous row's lower one reuses it (no load).
+    int sy0[kResizeRows], sy1[kResizeRows], b0[kResizeRows], b1[kResizeRows];
+    bool live[kResizeRows], need0[kResizeRows], need1[kResizeRows];
+#pragma unroll
     for (int r = 0; r < kResizeRows; ++r) {
-        const int y = yFirst + r;
-        if (y >= D.h) break;
-        const int sy0 = yofs[D.tapY + y];
-        const int sy1 = min(sy0 + 1, S.h - 1);
+        const int y = min(yFirst + r, D.h - 1);
+        live[r] = yFirst + r < D.h;
+        sy0[r] = yofs[D.tapY + y];
+        sy1[r] = min(sy0[r] + 1, S.h - 1);
         const uint32_t yc = ycoef[D.tapY + y];
-        const int b0 = (int)(yc & 0xFFFFu), b1 = (int)(yc >> 16);
-        const uint8_t* r0 = src + (long long)sy0 * S.pitch;
-        const uint8_t* r1 = src + (long long)sy1 * S.pitch;
-        uint32_t packed = 0;
-        if (window) {
-            const uint2 g0 = (sy0 == heldRow) ? held : resize_gather(r0, base, sh, sel0, sel1);
-            const uint2 g1 = (sy1 == sy0) ? g0 : resize_gather(r1, base, sh, sel0, sel1);
-            heldRow = sy1; held = g1;
+        b0[r] = (int)(yc & 0xFFFFu); b1[r] = (int)(yc >> 16);
+        need0[r] = live[r] && (r == 0 || sy0[r] != sy1[r - 1]);
+        need1[r] = live[r] && sy1[r] != sy0[r];
+    }
+    if (window) {
+        ResizeRaw raw0[kResizeRows], raw1[kResizeRows];
+#pragma unroll
+        for (int r = 0; r < kResizeRows; ++r) {
+            raw0[r] = raw1[r] = ResizeRaw{0u, 0u, 0u};
+            if (need0[r]) raw0[r] = resize_load(src + (long long)sy0[r] * S.pitch, base);
+            if (need1[r]) raw1[r] = resize_load(src + (long long)sy1[r] * S.pitch, base);
+        }
+        uint2 prev = make_uint2(0u, 0u);
+#pragma unroll
+        for (int r = 0; r < kResizeRows; ++r) {
+            if (!live[r]) break;
+            const uint2 g0 = need0[r] ? resize_gather(raw0[r], sh, sel0, sel1) : prev;
+            const uint2 g1 = need1[r] ? resize_gather(raw1[r], sh, sel0, sel1) : g0;
+            prev = g1;
+            uint32_t packed = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int t0 = (int)((g0.x >> (8 * i)) & 255u) * a0[i] + (int)((g0.y >> (8 * i)) & 255u) * a1[i];
                 const int t1 = (int)((g1.x >> (8 * i)) & 255u) * a0[i] + (int)((g1.y >> (8 * i)) & 255u) * a1[i];
-                const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+                const int v = (((b0[r] * (t0 >> 4)) >> 16) + ((b1[r] * (t1 >> 4)) >> 16) + 2) >> 2;
                 packed |= (uint32_t)(v & 255) << (8 * i);
             }
-        } else {
+            *reinterpret_cast<uint32_t*>(dst + (long long)(yFirst + r) * D.pitch + x4) = packed;   // pitch padding absorbs the tail
+        }
+    } else {
+        for (int r = 0; r < kResizeRows; ++r) {
+            if (!live[r]) break;
+            const uint8_t* r0 = src + (long long)sy0[r] * S.pitch;
+            const uint8_t* r1 = src + (long long)sy1[r] * S.pitch;
+            uint32_t packed = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int sx0 = so[i], sx1 = min(sx0 + 1, S.w - 1);
                 const int t0 = r0[sx0] * a0[i] + r0[sx1] * a1[i];
                 const int t1 = r1[sx0] * a0[i] + r1[sx1] * a1[i];
-                const int v = (((b0 * (t0 >> 4)) >> 16) + ((b1 * (t1 >> 4)) >> 16) + 2) >> 2;
+                const int v = (((b0[r] * (t0 >> 4)) >> 16) + ((b1[r] * (t1 >> 4)) >> 16) + 2) >> 2;
                 packed |= (uint32_t)(v & 255) << (8 * i);
             }
+            *reinterpret_cast<uint32_t*>(dst + (long long)(yFirst + r) * D.pitch + x4) = packed;
         }
-        *reinterpret_cast<uint32_t*>(dst + (long long)y * D.pitch + x4) = packed;   // pitch padding absorbs the tail
     }
 }
 
