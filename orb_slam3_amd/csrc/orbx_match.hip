@@ -449,7 +449,6 @@ __global__ __launch_bounds__(64 * kStWaves) void k_stereo_rows(const OrbxFrameGe
     __shared__ int s_fill[kStBuckets];
     __shared__ uint32_t s_patch[kStWaves][11 * 4 + 11 * 8];   // left rows: 4 dwords each, right rows: 8 dwords each
     __shared__ int s_part[kStWaves][128];
-    __shared__ unsigned int s_keys[kStWaves][kStPerWave];
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -551,53 +550,83 @@ __global__ __launch_bounds__(64 * kStWaves) void k_stereo_rows(const OrbxFrameGe
         }
     }
 
-    // (b) sub-pixel refinement by correlation on the pyramid level of the left keypoint
+    // (b) sub-pixel refinement by correlation on the pyramid level of the left keypoint.  The global reads of the
+    // wave's keypoints are issued together, stage by stage (keypoint records, then the pixel windows), so that the
+    // wave pays each memory round trip once and not once per keypoint.
     uint32_t* patch = s_patch[wv];
     int* part = s_part[wv];
+    unsigned int keyOf[kStPerWave];
 #pragma unroll
     for (int k = 0; k < kStPerWave; ++k) {
         unsigned int key = bestKey[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) key = min(key, (unsigned int)__shfl_xor((int)key, off));
-        if (lane == 0) s_keys[wv][k] = key;
+        keyOf[k] = (unsigned int)__builtin_amdgcn_readfirstlane((int)key);
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-#pragma unroll 1
+    // stage 1: the left keypoint and the x of its best right keypoint (wave-uniform addresses)
+    bool ok[kStPerWave];
+    orbx_keypoint kpOf[kStPerWave];
+    float uR0Of[kStPerWave];
+#pragma unroll
     for (int k = 0; k < kStPerWave; ++k) {
-        const unsigned int key = s_keys[wv][k];
-        if (key == 0xFFFFFFFFu) continue;
-        const int bestDist = (int)(key >> 20), bestIdxR = (int)(key & 0xFFFFFu);
-        if (!(bestDist < 75)) continue;   // thOrbDist = (TH_HIGH + TH_LOW) / 2
+        ok[k] = keyOf[k] != 0xFFFFFFFFu && (int)(keyOf[k] >> 20) < 75;   // thOrbDist = (TH_HIGH + TH_LOW) / 2
         const long long rowL = (long long)frame * capacity + iL0 + k;
-        const orbx_keypoint kp = kpsL[rowL];
-        const float uL = kp.x;
+        const int bestIdxR = ok[k] ? (int)(keyOf[k] & 0xFFFFFu) : 0;
+        kpOf[k] = kpsL[ok[k] ? rowL : (long long)frame * capacity];
+        uR0Of[k] = kpsR[(long long)frame * capacity + bestIdxR].x;
+    }
+    // stage 2: window geometry, then 11 x 4 dwords of the left patch and 11 x 7 dwords of the right strip
+    // (121 dwords: lane i takes dwords i and i + 64)
+    float suR0Of[kStPerWave];
+    int shLOf[kStPerWave], offROf[kStPerWave];
+    uint32_t pa[kStPerWave], pb[kStPerWave];
+#pragma unroll
+    for (int k = 0; k < kStPerWave; ++k) {
+        pa[k] = pb[k] = 0u; suR0Of[k] = 0.f; shLOf[k] = 0; offROf[k] = 0;
+        if (!ok[k]) continue;
+        const orbx_keypoint kp = kpOf[k];
         const OrbxLevelGeo& G = geo->lv[kp.octave];
-        const float uR0 = kpsR[(long long)frame * capacity + bestIdxR].x;
         const float sInv = G.invScale;
-        const float suL = roundf(__fmul_rn(kp.x, sInv)), svL = roundf(__fmul_rn(kp.y, sInv)), suR0 = roundf(__fmul_rn(uR0, sInv));
+        const float suL = roundf(__fmul_rn(kp.x, sInv)), svL = roundf(__fmul_rn(kp.y, sInv)), suR0 = roundf(__fmul_rn(uR0Of[k], sInv));
         const int w = 5, L = 5;
         const float iniu = __fsub_rn(__fadd_rn(suR0, (float)L), (float)w);
         const float endu = __fadd_rn(__fadd_rn(__fadd_rn(suR0, (float)L), (float)w), 1.f);
-        if (iniu < 0 || endu >= (float)G.w) continue;
+        if (iniu < 0 || endu >= (float)G.w) { ok[k] = false; continue; }
         const int y0 = (int)(svL - w), xl0 = (int)(suL - w), xr0 = (int)(suR0 - w) - L;   // xr0: first column of the right strip
         // the windows of keypoints produced by the extractor always lie inside the level; anything else is not matched
-        if (y0 < 0 || y0 + 11 > G.h || xl0 < 0 || xl0 + 11 > G.w || xr0 < 0 || xr0 + 21 > G.w) continue;
+        if (y0 < 0 || y0 + 11 > G.h || xl0 < 0 || xl0 + 11 > G.w || xr0 < 0 || xr0 + 21 > G.w) { ok[k] = false; continue; }
         const uint8_t* imL = pv.left + (long long)frame * pv.frameStride + G.off;
         const uint8_t* imR = pv.right + (long long)frame * pv.frameStride + G.off;
         const int xla = xl0 & ~3, xra = xr0 & ~3;
-        // 11 x 4 dwords of the left patch and 11 x 7 dwords of the right strip, one load per lane and pass
-        for (int i = lane; i < 11 * 4 + 11 * 7; i += 64) {
+        suR0Of[k] = suR0; shLOf[k] = xl0 - xla; offROf[k] = xr0 - xra;
+        auto fetch = [&](int i) -> uint32_t {
             if (i < 44) {
                 const int r = i >> 2, d = i & 3;
-                patch[i] = *reinterpret_cast<const uint32_t*>(imL + (long long)(y0 + r) * G.pitch + xla + 4 * d);
-            } else {
-                const int t = i - 44, r = t / 7, d = t - r * 7;
-                patch[44 + r * 8 + d] = *reinterpret_cast<const uint32_t*>(imR + (long long)(y0 + r) * G.pitch + xra + 4 * d);
+                return *reinterpret_cast<const uint32_t*>(imL + (long long)(y0 + r) * G.pitch + xla + 4 * d);
             }
+            const int t = i - 44, r = t / 7, d = t - r * 7;
+            return *reinterpret_cast<const uint32_t*>(imR + (long long)(y0 + r) * G.pitch + xra + 4 * d);
+        };
+        pa[k] = fetch(lane);
+        if (lane + 64 < 11 * 4 + 11 * 7) pb[k] = fetch(lane + 64);
+    }
+    // stage 3: correlation, one keypoint after the other through the wave's LDS patch
+#pragma unroll
+    for (int k = 0; k < kStPerWave; ++k) {
+        if (!ok[k]) continue;
+        const int L = 5;
+        const long long rowL = (long long)frame * capacity + iL0 + k;
+        const float uL = kpOf[k].x;
+        const OrbxLevelGeo& G = geo->lv[kpOf[k].octave];
+        const float suR0 = suR0Of[k];
+        {
+            const int i0 = lane, i1 = lane + 64;
+            patch[i0 < 44 ? i0 : 44 + ((i0 - 44) / 7) * 8 + (i0 - 44) % 7] = pa[k];
+            if (i1 < 11 * 4 + 11 * 7) patch[44 + ((i1 - 44) / 7) * 8 + (i1 - 44) % 7] = pb[k];
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         // item = (row dy, shift s): SAD of 11 pixels = three v_sad_u8 over byte windows
-        const int shL = xl0 - xla, offR = xr0 - xra;
+        const int shL = shLOf[k], offR = offROf[k];
         for (int p = lane; p < 121; p += 64) {
             const int dy = p / 11, sft = p - dy * 11;
             const uint32_t* lp = patch + dy * 4;
