@@ -429,8 +429,71 @@ struct OrbxPyrView {
 
 constexpr int kStWaves = 8;          // waves per workgroup
 constexpr int kStPerWave = 4;        // left keypoints handled by one wave, one after the other
-constexpr int kStChunk = 2048;       // right keypoints staged in LDS at a time
 constexpr int kStBuckets = 256;      // row buckets of the staged keypoints (multiple of 64)
+
+// Right keypoints of one frame bucketed by image row (counting sort), once per frame: for every entry the row band
+// minr | (maxr + 1) << 16 of Frame.cc:980-990, its x, and (octave << 20) | index.  A left keypoint then reads only
+// the buckets its row can touch.  Order inside a bucket is arbitrary (the match is a lexicographic minimum).
+struct OrbxStereoSorted {
+    uint32_t* rows;     // capacity entries per frame
+    float* x;
+    uint32_t* octIdx;
+    int* start;         // kStBuckets + 1 per frame
+};
+
+__device__ __forceinline__ int stereo_bucket_shift(int nRows) {
+    int shift = 3;
+    while (((nRows - 1) >> shift) >= kStBuckets) ++shift;
+    return shift;
+}
+
+__global__ __launch_bounds__(512) void k_stereo_prep(const OrbxFrameGeo* __restrict__ geo,
+                                                     const orbx_keypoint* __restrict__ kpsR,
+                                                     const int* __restrict__ countsR, int capacity, OrbxStereoSorted out) {
+    __shared__ int s_start[kStBuckets + 1];
+    __shared__ int s_fill[kStBuckets];
+    const int frame = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int nR = min(countsR[2 * frame], capacity);
+    const int nRows = geo->lv[0].h;
+    const int shift = stereo_bucket_shift(nRows);
+    const orbx_keypoint* KR = kpsR + (long long)frame * capacity;
+    for (int i = tid; i < kStBuckets; i += 512) { s_start[i + 1] = 0; s_fill[i] = 0; }
+    if (tid == 0) s_start[0] = 0;
+    __syncthreads();
+    for (int j = tid; j < nR; j += 512) {
+        const int b = min(max((int)KR[j].y, 0), nRows - 1) >> shift;
+        atomicAdd(&s_start[b + 1], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {   // inclusive scan of the bucket counts: kStBuckets / 64 per lane
+        constexpr int per = kStBuckets / 64;
+        int v[per], sum = 0;
+#pragma unroll
+        for (int q = 0; q < per; ++q) { v[q] = s_start[1 + lane * per + q]; sum += v[q]; }
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        int run = incl - sum;
+#pragma unroll
+        for (int q = 0; q < per; ++q) { run += v[q]; s_start[1 + lane * per + q] = run; }
+    }
+    __syncthreads();
+    uint32_t* rows = out.rows + (long long)frame * capacity;
+    float* xs = out.x + (long long)frame * capacity;
+    uint32_t* oi = out.octIdx + (long long)frame * capacity;
+    for (int j = tid; j < nR; j += 512) {
+        const orbx_keypoint kr = KR[j];
+        const int b = min(max((int)kr.y, 0), nRows - 1) >> shift;
+        const int slot = s_start[b] + atomicAdd(&s_fill[b], 1);
+        const float r = __fmul_rn(2.0f, geo->lv[kr.octave].scale);
+        const int maxr = min(max((int)ceilf(__fadd_rn(kr.y, r)), -1), 65534);
+        const int minr = min(max((int)floorf(__fsub_rn(kr.y, r)), 0), 65535);   // rows are >= 0: clamping keeps the test
+        rows[slot] = (uint32_t)minr | ((uint32_t)(maxr + 1) << 16);
+        xs[slot] = kr.x;
+        oi[slot] = ((uint32_t)kr.octave << 20) | (uint32_t)j;
+    }
+    for (int i = tid; i <= kStBuckets; i += 512) out.start[(long long)frame * (kStBuckets + 1) + i] = s_start[i];
+}
 
 __global__ __launch_bounds__(64 * kStWaves) void k_stereo_rows(const OrbxFrameGeo* __restrict__ geo, OrbxPyrView pv,
                                                      const orbx_keypoint* __restrict__ kpsL, const uint32_t* __restrict__ descL,
@@ -438,31 +501,26 @@ __global__ __launch_bounds__(64 * kStWaves) void k_stereo_rows(const OrbxFrameGe
                                                      const orbx_keypoint* __restrict__ kpsR, const uint32_t* __restrict__ descR,
                                                      const int* __restrict__ countsR, int capacity, float mbf, float mb,
                                                      float* __restrict__ uRight, float* __restrict__ depth,
-                                                     int* __restrict__ sadOut) {
-    // The row band, octave and x of every right keypoint are staged once per workgroup, bucketed by
-    // image row (counting sort in LDS); a left keypoint scans only the buckets its row band can touch.
-    __shared__ uint32_t s_rows[kStChunk];            // minr | (maxr + 1) << 16 (Frame.cc:980-990)
-    __shared__ float s_x[kStChunk];
-    __shared__ uint16_t s_idx[kStChunk];             // index inside the chunk
-    __shared__ uint8_t s_oct[kStChunk];
-    __shared__ int s_start[kStBuckets + 1];
-    __shared__ int s_fill[kStBuckets];
+                                                     int* __restrict__ sadOut, OrbxStereoSorted sorted) {
     __shared__ uint32_t s_patch[kStWaves][11 * 4 + 11 * 8];   // left rows: 4 dwords each, right rows: 8 dwords each
     __shared__ int s_part[kStWaves][128];
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nL = countsL[2 * frame], nR = countsR[2 * frame];
+    const int nL = countsL[2 * frame];
     const int nRows = geo->lv[0].h;
     const float minZ = mb, minD = 0.f;
     const float maxD = __fdiv_rn(mbf, minZ);
     const int iL0 = (blockIdx.x * kStWaves + wv) * kStPerWave;
-    if (blockIdx.x * kStWaves * kStPerWave >= nL) return;     // whole workgroup idle (uniform)
+    if (iL0 >= nL) return;     // nothing shared between the waves of a workgroup: idle waves leave
     // bucket = row >> shift, at most kStBuckets buckets; a right keypoint at row y can only match left
     // rows within reach = ceil(2 * largest scale) + 1 of y
-    int shift = 3;
-    while (((nRows - 1) >> shift) >= kStBuckets) ++shift;
+    const int shift = stereo_bucket_shift(nRows);
     const int reach = (int)ceilf(__fmul_rn(2.0f, geo->lv[geo->nlevels - 1].scale)) + 1;
+    const uint32_t* sRows = sorted.rows + (long long)frame * capacity;
+    const float* sX = sorted.x + (long long)frame * capacity;
+    const uint32_t* sOctIdx = sorted.octIdx + (long long)frame * capacity;
+    const int* sStart = sorted.start + (long long)frame * (kStBuckets + 1);
 
     // per left keypoint of this wave (all wave-uniform)
     int rowOf[kStPerWave], levelOf[kStPerWave];
@@ -485,69 +543,64 @@ __global__ __launch_bounds__(64 * kStWaves) void k_stereo_rows(const OrbxFrameGe
         }
     }
 
-    // (a) lexicographic min over (distance, right index) of the gated candidates
-    for (int c0 = 0; c0 < nR; c0 += kStChunk) {
-        const int n = min(kStChunk, nR - c0);
-        const orbx_keypoint* KR = kpsR + (long long)frame * capacity + c0;
-        __syncthreads();
-        for (int i = threadIdx.x; i < kStBuckets; i += 64 * kStWaves) { s_start[i + 1] = 0; s_fill[i] = 0; }
-        if (threadIdx.x == 0) s_start[0] = 0;
-        __syncthreads();
-        for (int j = threadIdx.x; j < n; j += 64 * kStWaves) {
-            const int b = min(max((int)KR[j].y, 0), nRows - 1) >> shift;
-            atomicAdd(&s_start[b + 1], 1);
+    // (a) lexicographic min over (distance, right index) of the gated candidates.  The wave's keypoints go through
+    // the two dependent reads (bucket entries, then the descriptors of the entries that pass the gates) side by
+    // side: first 64 entries of every keypoint's range at once, longer ranges continue one keypoint at a time.
+    int jBeg[kStPerWave], jEnd[kStPerWave];
+    uint32_t rrOf[kStPerWave], oiOf[kStPerWave];
+    float xOf[kStPerWave];
+#pragma unroll
+    for (int k = 0; k < kStPerWave; ++k) {
+        jBeg[k] = 0; jEnd[k] = 0; rrOf[k] = 0u; oiOf[k] = 0u; xOf[k] = 0.f;
+        if (rowOf[k] < 0) continue;
+        const int bLo = max(rowOf[k] - reach, 0) >> shift, bHi = min(rowOf[k] + reach, nRows - 1) >> shift;
+        jBeg[k] = sStart[bLo]; jEnd[k] = sStart[bHi + 1];
+        const int t = jBeg[k] + lane;
+        if (t < jEnd[k]) { rrOf[k] = sRows[t]; oiOf[k] = sOctIdx[t]; xOf[k] = sX[t]; }
+    }
+    uint32_t dr[kStPerWave][8];
+    bool pass[kStPerWave];
+#pragma unroll
+    for (int k = 0; k < kStPerWave; ++k) {
+        const int row = rowOf[k], lvl = levelOf[k], oc = (int)(oiOf[k] >> 20);
+        pass[k] = jBeg[k] + lane < jEnd[k] && !(row < (int)(rrOf[k] & 0xFFFFu) || row + 1 > (int)(rrOf[k] >> 16)) &&
+                  !(oc < lvl - 1 || oc > lvl + 1) && (xOf[k] >= minUOf[k] && xOf[k] <= maxUOf[k]);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dr[k][q] = 0u;
+        if (pass[k]) {
+            const uint32_t* dR = descR + ((long long)frame * capacity + (int)(oiOf[k] & 0xFFFFFu)) * 8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dr[k][q] = dR[q];
         }
-        __syncthreads();
-        if (wv == 0) {   // inclusive scan of the bucket counts: kStBuckets / 64 per lane
-            constexpr int per = kStBuckets / 64;
-            int v[per], sum = 0;
+    }
 #pragma unroll
-            for (int q = 0; q < per; ++q) { v[q] = s_start[1 + lane * per + q]; sum += v[q]; }
-            int incl = sum;
+    for (int k = 0; k < kStPerWave; ++k) {
+        if (rowOf[k] < 0) continue;
+        const uint32_t* dL = descL + ((long long)frame * capacity + iL0 + k) * 8;
+        const int row = rowOf[k], lvl = levelOf[k];
+        unsigned int key = bestKey[k];
+        if (pass[k]) {
+            int d = 0;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
-            int run = incl - sum;
-#pragma unroll
-            for (int q = 0; q < per; ++q) { run += v[q]; s_start[1 + lane * per + q] = run; }
+            for (int q = 0; q < 8; ++q) d += __popc(dL[q] ^ dr[k][q]);
+            if (d < 100) key = min(key, ((unsigned int)d << 20) | (oiOf[k] & 0xFFFFFu));
         }
-        __syncthreads();
-        for (int j = threadIdx.x; j < n; j += 64 * kStWaves) {
-            const orbx_keypoint kr = KR[j];
-            const int b = min(max((int)kr.y, 0), nRows - 1) >> shift;
-            const int slot = s_start[b] + atomicAdd(&s_fill[b], 1);
-            const float r = __fmul_rn(2.0f, geo->lv[kr.octave].scale);
-            const int maxr = min(max((int)ceilf(__fadd_rn(kr.y, r)), -1), 65534);
-            const int minr = min(max((int)floorf(__fsub_rn(kr.y, r)), 0), 65535);   // rows are >= 0: clamping keeps the test
-            s_rows[slot] = (uint32_t)minr | ((uint32_t)(maxr + 1) << 16);
-            s_x[slot] = kr.x;
-            s_oct[slot] = (uint8_t)kr.octave;
-            s_idx[slot] = (uint16_t)j;
-        }
-        __syncthreads();
+        for (int t = jBeg[k] + 64 + lane; t < jEnd[k]; t += 64) {
+            const uint32_t rr = sRows[t];
+            if (row < (int)(rr & 0xFFFFu) || row + 1 > (int)(rr >> 16)) continue;
+            const uint32_t oi = sOctIdx[t];
+            const int oc = (int)(oi >> 20);
+            if (oc < lvl - 1 || oc > lvl + 1) continue;
+            const float x = sX[t];
+            if (!(x >= minUOf[k] && x <= maxUOf[k])) continue;
+            const int j = (int)(oi & 0xFFFFFu);
+            const uint32_t* dR = descR + ((long long)frame * capacity + j) * 8;
+            int d = 0;
 #pragma unroll
-        for (int k = 0; k < kStPerWave; ++k) {
-            if (rowOf[k] < 0) continue;
-            const uint32_t* dL = descL + ((long long)frame * capacity + iL0 + k) * 8;
-            const int row = rowOf[k], lvl = levelOf[k];
-            const int bLo = max(row - reach, 0) >> shift, bHi = min(row + reach, nRows - 1) >> shift;
-            const int jEnd = s_start[bHi + 1];
-            unsigned int key = bestKey[k];
-            for (int t = s_start[bLo] + lane; t < jEnd; t += 64) {
-                const uint32_t rr = s_rows[t];
-                if (row < (int)(rr & 0xFFFFu) || row + 1 > (int)(rr >> 16)) continue;
-                const int oc = s_oct[t];
-                if (oc < lvl - 1 || oc > lvl + 1) continue;
-                const float x = s_x[t];
-                if (!(x >= minUOf[k] && x <= maxUOf[k])) continue;
-                const int j = c0 + s_idx[t];
-                const uint32_t* dR = descR + ((long long)frame * capacity + j) * 8;
-                int d = 0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) d += __popc(dL[q] ^ dR[q]);
-                if (d < 100) key = min(key, ((unsigned int)d << 20) | (unsigned int)j);
-            }
-            bestKey[k] = key;
+            for (int q = 0; q < 8; ++q) d += __popc(dL[q] ^ dR[q]);
+            if (d < 100) key = min(key, ((unsigned int)d << 20) | (unsigned int)j);
         }
+        bestKey[k] = key;
     }
 
     // (b) sub-pixel refinement by correlation on the pyramid level of the left keypoint.  The global reads of the
@@ -758,12 +811,23 @@ extern "C" orbx_status orbx_stereo_match_batch_device(orbx_extractor* left, orbx
     pv.left = orbx_internal_pyramid(left);
     pv.right = orbx_internal_pyramid(right);
     pv.frameStride = gl->pyrBytes;
-    int* d_sad = (int*)orbx_internal_scratch(left, (size_t)n_frames * capacity * sizeof(int));
-    if (!d_sad) { orbx_set_error("cannot allocate the SAD scratch buffer"); return ORBX_ERR_HIP; }
+    // scratch: the SAD of every left keypoint, then the row-sorted right keypoints of every frame
+    const size_t perFrame = (size_t)capacity * 4;
+    const size_t startBytes = (((size_t)n_frames * (kStBuckets + 1) * sizeof(int)) + 255) & ~(size_t)255;
+    char* scratch = (char*)orbx_internal_scratch(left, (size_t)n_frames * perFrame * 4 + startBytes);
+    if (!scratch) { orbx_set_error("cannot allocate the stereo scratch buffer"); return ORBX_ERR_HIP; }
+    int* d_sad = (int*)scratch;
+    OrbxStereoSorted sorted;
+    sorted.rows = (uint32_t*)(scratch + (size_t)n_frames * perFrame);
+    sorted.x = (float*)(scratch + (size_t)n_frames * perFrame * 2);
+    sorted.octIdx = (uint32_t*)(scratch + (size_t)n_frames * perFrame * 3);
+    sorted.start = (int*)(scratch + (size_t)n_frames * perFrame * 4);
+    hipLaunchKernelGGL(k_stereo_prep, dim3(n_frames), dim3(512), 0, st, orbx_internal_geo_device(left), d_kps_right,
+                       d_counts_right, capacity, sorted);
     hipLaunchKernelGGL(k_stereo_rows, dim3((capacity + kStWaves * kStPerWave - 1) / (kStWaves * kStPerWave), n_frames),
                        dim3(64 * kStWaves), 0, st, orbx_internal_geo_device(left), pv,
                        d_kps_left, (const uint32_t*)d_desc_left, d_counts_left, d_kps_right, (const uint32_t*)d_desc_right,
-                       d_counts_right, capacity, mbf, mb, d_u_right, d_depth, d_sad);
+                       d_counts_right, capacity, mbf, mb, d_u_right, d_depth, d_sad, sorted);
     hipLaunchKernelGGL(k_stereo_median, dim3(n_frames), dim3(256), 0, st, d_counts_left, capacity, d_u_right, d_depth, d_sad);
     ORBX_HIP_TRY(hipGetLastError());
     return ORBX_OK;
