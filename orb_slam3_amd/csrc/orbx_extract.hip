@@ -580,6 +580,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
 // the highest response, the earliest in emission order among equals.
 // ======================================================================================
 constexpr int kQtThreads = 512;
+constexpr int kQtRegKeys = 8;     // keys per thread whose position and node stay in registers
 
 struct QtBox { short ulx, uly, brx, bry; };
 
@@ -665,12 +666,35 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
     for (int i = tid; i < nIni; i += kQtThreads) child[i] = 0;
     if (tid == 0) { s_size = 0; s_done = 0; s_bad = 0; }
     __syncthreads();
-    for (int i = tid; i < n; i += kQtThreads) {
-        int r = (int)__fdiv_rn(C[i].x, hX);
-        r = min(max(r, 0), nIni - 1);
-        KN[i] = (uint16_t)r;
-        atomicAdd(&child[r], 1);
+    // The position and the node of the first kQtRegKeys keys of every thread stay in registers for the whole
+    // kernel (all keys of a 752 x 480 level); the sweeps below then touch global memory only for the keys beyond
+    // that, whose node index lives in keyNode.
+    float kx[kQtRegKeys], ky[kQtRegKeys];
+    int kn[kQtRegKeys];
+#pragma unroll
+    for (int k = 0; k < kQtRegKeys; ++k) {
+        const int i = tid + k * kQtThreads;
+        kx[k] = 0.f; ky[k] = 0.f; kn[k] = 0;
+        if (i < n) { kx[k] = C[i].x; ky[k] = C[i].y; }
     }
+    // fn(x, y, node&) for every key of this thread
+    auto for_keys = [&](auto&& fn) {
+#pragma unroll
+        for (int k = 0; k < kQtRegKeys; ++k)
+            if (tid + k * kQtThreads < n) fn(kx[k], ky[k], kn[k]);
+        for (int i = tid + kQtRegKeys * kQtThreads; i < n; i += kQtThreads) {
+            const int before = KN[i];
+            int nd = before;
+            fn(C[i].x, C[i].y, nd);
+            if (nd != before) KN[i] = (uint16_t)nd;
+        }
+    };
+    for_keys([&](float x, float, int& nd) {
+        int r = (int)__fdiv_rn(x, hX);
+        r = min(max(r, 0), nIni - 1);
+        nd = r + 0x10000;      // marks "written" for the global tail (the stored value is the low 16 bits)
+        atomicAdd(&child[r], 1);
+    });
     __syncthreads();
     if (tid == 0) {
         int sz = 0;
@@ -687,7 +711,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
         s_size = sz;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += kQtThreads) KN[i] = (uint16_t)scanv[KN[i]];
+    for_keys([&](float, float, int& nd) { nd = scanv[nd & 0xFFFF]; });
     __syncthreads();
 
     // ---- split loop ------------------------------------------------------------------
@@ -698,10 +722,9 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
         // (1) per-child key counts of every node that can still be split
         for (int i = tid; i < 4 * size; i += kQtThreads) child[i] = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += kQtThreads) {
-            const int nd = KN[i];
-            if (cnt[nd] > 1) atomicAdd(&child[4 * nd + qt_quadrant(box[nd], C[i].x, C[i].y)], 1);
-        }
+        for_keys([&](float x, float y, int& nd) {
+            if (cnt[nd] > 1) atomicAdd(&child[4 * nd + qt_quadrant(box[nd], x, y)], 1);
+        });
         __syncthreads();
 
         // (2) choose the nodes to split and the creation order of their children
@@ -794,11 +817,9 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
         }
         __syncthreads();
         // (5) move the keys
-        for (int i = tid; i < n; i += kQtThreads) {
-            const int nd = KN[i];
-            if (base[nd] < 0) KN[i] = (uint16_t)child[4 * nd];
-            else KN[i] = (uint16_t)child[4 * nd + qt_quadrant(box[nd], C[i].x, C[i].y)];
-        }
+        for_keys([&](float x, float y, int& nd) {
+            nd = (base[nd] < 0) ? child[4 * nd] : child[4 * nd + qt_quadrant(box[nd], x, y)];
+        });
         __syncthreads();
         { QtBox* t = box; box = nbox; nbox = t; int* u = cnt; cnt = ncnt; ncnt = u; }
 
@@ -843,15 +864,23 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
     }
     for (int p = tid; p < size; p += kQtThreads) sortbuf[p] = 0ull;
     __syncthreads();
+    auto node_of = [&](int i) {      // i = tid + k * kQtThreads
+        int nd = 0;
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < kQtRegKeys; ++k)
+            if (i == tid + k * kQtThreads) { nd = kn[k]; found = true; }
+        return found ? nd : (int)KN[i];
+    };
     for (int i = tid; i < n; i += kQtThreads) {
         const unsigned long long key = ((unsigned long long)(uint32_t)C[i].response << 32) | (uint32_t)(~C[i].order);
-        atomicMax(&sortbuf[KN[i]], key);
+        atomicMax(&sortbuf[node_of(i)], key);
     }
     __syncthreads();
     for (int i = tid; i < n; i += kQtThreads) {
         const OrbxCand c = C[i];
         const unsigned long long key = ((unsigned long long)(uint32_t)c.response << 32) | (uint32_t)(~c.order);
-        const int nd = KN[i];
+        const int nd = node_of(i);
         if (sortbuf[nd] == key) {
             OrbxLevelKp k;
             k.x = __fadd_rn(c.x, (float)kOrbxMinBorder);
