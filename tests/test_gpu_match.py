@@ -146,6 +146,43 @@ def test_stereo_match_matches_oracle(oracle, seed):
     assert np.array_equal(d, depth)
 
 
+def test_kitti_style_stereo_and_tumvi_fisheye_knn(oracle):
+    """The other two stereo configurations of the metric: 1241 x 376 with 2000 features through the row-band
+    search, and 512 x 512 fisheye
+    frames matched by brute force with the 0.7 ratio test (Frame.cc:1309-1320)."""
+    A = _gpu()
+    L, R = synth.stereo_pair(1241, 376, 17)
+    eL, eR = oracle.Extractor(2000), oracle.Extractor(2000)
+    kL, dL, _ = eL(L, (0, 0))
+    kR, dR, _ = eR(R, (0, 0))
+    pl = [eL.pyramid_level(l) for l in range(8)]
+    pr = [eR.pyramid_level(l) for l in range(8)]
+    mbf, fx = 386.1448, 718.856                      # KITTI 00-02 calibration
+    uR, depth, _, _ = oracle.stereo_match(kL, dL, kR, dR, pl, pr, eL.scale_factors, eL.inv_scale_factors, mbf, mbf / fx)
+    gl = A.ORBextractor(2000, 1.2, 8, 20, 7, 1241, 376)
+    gr = A.ORBextractor(2000, 1.2, 8, 20, 7, 1241, 376)
+    kgl, dgl, _ = gl(L, (0, 0))
+    kgr, dgr, _ = gr(R, (0, 0))
+    assert np.array_equal(kgl, kL) and np.array_equal(kgr, kR) and len(kR) > 1500
+    u, d = A.compute_stereo_matches(gl, gr, kgl, dgl, kgr, dgr, mbf, mbf / fx)
+    assert (uR >= 0).sum() > 50 and np.array_equal(u, uR) and np.array_equal(d, depth)
+    # TUM-VI style: two 512 x 512 frames, knnMatch(k = 2) + ratio 0.7
+    F1, F2 = synth.stereo_pair(512, 512, 18)
+    o1, o2 = oracle.Extractor(1000), oracle.Extractor(1000)
+    k1, d1, _ = o1(F1, (0, 511))
+    k2, d2, _ = o2(F2, (0, 511))
+    g1 = A.ORBextractor(1000, 1.2, 8, 20, 7, 512, 512)
+    a1, b1, m1 = g1(F1, (0, 511))
+    a2, b2, m2 = g1(F2, (0, 511))
+    assert np.array_equal(b1, d1) and np.array_equal(b2, d2)
+    ref = oracle.knn2(d1, d2)
+    got = A.knn_match2(b1, b2)
+    assert np.array_equal(np.stack([got["idx0"], got["dist0"], got["idx1"], got["dist1"]], 1), ref)
+    good = A.fisheye_ratio_matches(got, 0.7)
+    want = np.nonzero((ref[:, 2] >= 0) & (ref[:, 1].astype(np.float64) < ref[:, 3].astype(np.float64) * 0.7))[0]
+    assert np.array_equal(good, want) and len(want) > 20
+
+
 def test_stereo_golden(golden_dir):
     A = _gpu()
     g = np.load(os.path.join(golden_dir, "stereo_euroc.npz"))
