@@ -898,7 +898,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
 // Keypoints whose level-0 x lies inside [lap0, lap1] fill the arrays from the back,
 // the others from the front, both in (level, list) order.
 // ======================================================================================
-constexpr int kLayThreads = 256;
+constexpr int kLayThreads = 1024;
 
 __global__ __launch_bounds__(kLayThreads) void k_layout(const OrbxFrameGeo* __restrict__ geo,
                                                         OrbxLevelKp* __restrict__ levelKps,
@@ -908,47 +908,50 @@ __global__ __launch_bounds__(kLayThreads) void k_layout(const OrbxFrameGeo* __re
     __shared__ int s_wave[kLayThreads / 64];
     __shared__ int s_running;
     const int frame = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
     const int nl = geo->nlevels;
     OrbxLevelKp* K = levelKps + (long long)frame * geo->kpTotal;
-    int total = 0;
-    for (int l = 0; l < nl; ++l) total += kpCount[frame * nl + l];
+    // keypoints of all levels as one sequence in (level, list) order: first[l] = keypoints before level l
+    int first[kOrbxMaxLevels + 1];
+    first[0] = 0;
+#pragma unroll
+    for (int l = 0; l < kOrbxMaxLevels; ++l) first[l + 1] = first[l] + (l < nl ? kpCount[frame * nl + l] : 0);
+    const int total = first[kOrbxMaxLevels];
     if (tid == 0) s_running = 0;
     __syncthreads();
     const bool overflow = total > capacity;
     if (overflow && tid == 0) atomicAdd(&err->out_overflow, 1);
-    for (int l = 0; l < nl; ++l) {
-        const OrbxLevelGeo& G = geo->lv[l];
-        const int cnt = kpCount[frame * nl + l];
-        for (int b = 0; b < cnt; b += kLayThreads) {
-            const int i = b + tid;
-            int mono = 0;
-            if (i < cnt) {
-                float x = K[G.kpOff + i].x;
-                if (l != 0) x = __fmul_rn(x, G.scale);
-                mono = (x >= (float)lap0 && x <= (float)lap1) ? 0 : 1;
-            }
-            // ordered rank of the mono flags inside this chunk
-            const unsigned long long bal = __ballot(mono);
-            const int lane = tid & 63, wv = tid >> 6;
-            const int before = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) s_wave[wv] = __popcll(bal);
-            __syncthreads();
-            int wbase = 0, chunkMono = 0;
-            for (int w = 0; w < kLayThreads / 64; ++w) { if (w < wv) wbase += s_wave[w]; chunkMono += s_wave[w]; }
-            const int running = s_running;          // mono keypoints before this chunk
-            const int seen = b;                      // keypoints of this level before this chunk
-            if (i < cnt && !overflow) {
-                const int monoBefore = running + wbase + before;
-                // keypoints before this one in (level, list) order:
-                int prior = seen + (tid);            // inside the level
-                for (int l2 = 0; l2 < l; ++l2) prior += kpCount[frame * nl + l2];
-                const int stereoBefore = prior - monoBefore;
-                K[G.kpOff + i].slot = mono ? monoBefore : (total - 1 - stereoBefore);
-            }
-            __syncthreads();
-            if (tid == 0) s_running = running + chunkMono;
-            __syncthreads();
+    for (int b = 0; b < total; b += kLayThreads) {
+        const int j = b + tid;
+        int mono = 0, l = 0, i = 0;
+        if (j < total) {
+#pragma unroll
+            for (int q = 1; q < kOrbxMaxLevels; ++q) l += (j >= first[q]) ? 1 : 0;
+            i = j;
+#pragma unroll
+            for (int q = 1; q < kOrbxMaxLevels; ++q) i = (l == q) ? j - first[q] : i;
+            const OrbxLevelGeo& G = geo->lv[l];
+            float x = K[G.kpOff + i].x;
+            if (l != 0) x = __fmul_rn(x, G.scale);
+            mono = (x >= (float)lap0 && x <= (float)lap1) ? 0 : 1;
         }
+        // ordered rank of the mono flags inside this chunk
+        const unsigned long long bal = __ballot(mono);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wv] = __popcll(bal);
+        __syncthreads();
+        int wbase = 0, chunkMono = 0;
+#pragma unroll
+        for (int w = 0; w < kLayThreads / 64; ++w) { const int c = s_wave[w]; wbase += (w < wv) ? c : 0; chunkMono += c; }
+        const int running = s_running;          // mono keypoints before this chunk
+        if (j < total && !overflow) {
+            const int monoBefore = running + wbase + before;
+            const int stereoBefore = j - monoBefore;      // j keypoints precede this one in (level, list) order
+            K[geo->lv[l].kpOff + i].slot = mono ? monoBefore : (total - 1 - stereoBefore);
+        }
+        __syncthreads();
+        if (tid == 0) s_running = running + chunkMono;
+        __syncthreads();
     }
     if (tid == 0) {
         counts[2 * frame] = overflow ? 0 : total;
