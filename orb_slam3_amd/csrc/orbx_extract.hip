@@ -189,18 +189,20 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__
 __global__ __launch_bounds__(256) void k_copy_level0(const OrbxFrameGeo* __restrict__ geo,
                                                      const uint8_t* __restrict__ images, long long rowStride,
                                                      long long imgStride, uint8_t* __restrict__ pyr,
-                                                     long long frameStride, int aligned16) {
+                                                     long long frameStride, int aligned16, int chunksPerRow) {
     const OrbxLevelGeo& D = geo->lv[0];
-    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    const int y = blockIdx.y;
-    if (x >= D.w) return;
-    const uint8_t* src = images + (long long)blockIdx.z * imgStride + (long long)y * rowStride + x;
-    uint8_t* dst = pyr + (long long)blockIdx.z * frameStride + D.off + (long long)y * D.pitch + x;
+    // the 16-byte chunks of a frame as one sequence: full workgroups whatever the image width
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = i / chunksPerRow;
+    if (y >= D.h) return;
+    const int x = (i - y * chunksPerRow) * 16;
+    const uint8_t* src = images + (long long)blockIdx.y * imgStride + (long long)y * rowStride + x;
+    uint8_t* dst = pyr + (long long)blockIdx.y * frameStride + D.off + (long long)y * D.pitch + x;
     if (aligned16 && x + 16 <= D.w) {
         *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
     } else {
         const int n = min(16, D.w - x);
-        for (int i = 0; i < n; ++i) dst[i] = src[i];
+        for (int k = 0; k < n; ++k) dst[k] = src[k];
     }
 }
 
@@ -1655,11 +1657,12 @@ extern "C" orbx_status orbx_extract_batch_device(orbx_extractor* ex, const uint8
     orbx_status s = ensure_geometry(ex, width, height);
     if (s != ORBX_OK) return s;
     hipStream_t st = (hipStream_t)stream;   // taken literally: NULL is the device's default stream
-    dim3 grid((width + 16 * 64 - 1) / (16 * 64), height, n_frames);
+    const int chunksPerRow = (width + 15) / 16;
+    dim3 grid((unsigned)(((long long)chunksPerRow * height + 255) / 256), n_frames);
     const int aligned16 = ((((uintptr_t)d_images) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
     mark(ex, st);
-    hipLaunchKernelGGL(k_copy_level0, grid, dim3(64), 0, st, ex->d_geo, d_images, (long long)row_stride,
-                       (long long)frame_stride, ex->d_pyr, ex->geo.pyrBytes, aligned16);
+    hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, st, ex->d_geo, d_images, (long long)row_stride,
+                       (long long)frame_stride, ex->d_pyr, ex->geo.pyrBytes, aligned16, chunksPerRow);
     return enqueue_batch(ex, n_frames, lap0, lap1, dyn_host, ndyn, d_keypoints, d_descriptors, capacity, d_counts, st);
 }
 
