@@ -97,13 +97,20 @@ __device__ __forceinline__ uint2 resize_gather(const ResizeRaw r, int sh, uint32
 __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__ geo, int level,
                                                 uint8_t* __restrict__ pyr, long long frameStride,
                                                 const int* __restrict__ xofs, const uint32_t* __restrict__ xcoef,
-                                                const int* __restrict__ yofs, const uint32_t* __restrict__ ycoef) {
+                                                const int* __restrict__ yofs, const uint32_t* __restrict__ ycoef,
+                                                int lanesPerRow, uint32_t lanesPerRowRcp) {
     const OrbxLevelGeo& S = geo->lv[level - 1];
     const OrbxLevelGeo& D = geo->lv[level];
-    const int fz = blockIdx.z;
-    const int yFirst = blockIdx.y * kResizeRows;
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (x4 >= D.w) return;
+    const int fz = blockIdx.y;
+    // (group of kResizeRows rows, 4-pixel column) as one sequence, so that the workgroups are full whatever the
+    // level's width; lanesPerRowRcp = floor(2^32 / lanesPerRow), one correction step makes the quotient exact
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t grp = __umulhi(i, lanesPerRowRcp);
+    uint32_t col = i - grp * (uint32_t)lanesPerRow;
+    if (col >= (uint32_t)lanesPerRow) { ++grp; col -= (uint32_t)lanesPerRow; }
+    const int yFirst = (int)grp * kResizeRows;
+    const int x4 = (int)col * 4;
+    if (yFirst >= D.h) return;
     const uint8_t* src = pyr + (long long)fz * frameStride + S.off;
     uint8_t* dst = pyr + (long long)fz * frameStride + D.off;
     const int4 o = *reinterpret_cast<const int4*>(xofs + D.tapX + x4);        // padded to a multiple of 4
@@ -129,14 +136,17 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__
     // together.  A row whose upper source row is the previous row's lower one reuses it (no load).
     int sy0[kResizeRows], sy1[kResizeRows], b0[kResizeRows], b1[kResizeRows];
     bool live[kResizeRows], need0[kResizeRows], need1[kResizeRows];
+    static_assert(kResizeRows == 4, "the vertical taps of a row group are one int4 / uint4");
+    const int4 oy = *reinterpret_cast<const int4*>(yofs + D.tapY + yFirst);       // padded to a multiple of 4
+    const uint4 cy = *reinterpret_cast<const uint4*>(ycoef + D.tapY + yFirst);
+    const int syv[4] = {oy.x, oy.y, oy.z, oy.w};
+    const uint32_t ycv[4] = {cy.x, cy.y, cy.z, cy.w};
 #pragma unroll
     for (int r = 0; r < kResizeRows; ++r) {
-        const int y = min(yFirst + r, D.h - 1);
         live[r] = yFirst + r < D.h;
-        sy0[r] = yofs[D.tapY + y];
+        sy0[r] = syv[r];
         sy1[r] = min(sy0[r] + 1, S.h - 1);
-        const uint32_t yc = ycoef[D.tapY + y];
-        b0[r] = (int)(yc & 0xFFFFu); b1[r] = (int)(yc >> 16);
+        b0[r] = (int)(ycv[r] & 0xFFFFu); b1[r] = (int)(ycv[r] >> 16);
         need0[r] = live[r] && (r == 0 || sy0[r] != sy1[r - 1]);
         need1[r] = live[r] && sy1[r] != sy0[r];
     }
@@ -1613,12 +1623,11 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
     if (ex->timing && ex->evUsed + kTimedStages + 1 > 4096 * (size_t)(kTimedStages + 1)) resolve_timing(ex);
     mark(ex, st);   // end of copy-in (its start is marked by the caller)
     for (int l = 1; l < nl; ++l) {
-        // a row needs w/4 lanes: size the workgroup to the row (whole waves, at most 256 lanes)
         const int lanes = (g.lv[l].w + 3) / 4;
-        const int bs = std::min(256, ((lanes + 63) / 64) * 64);
-        dim3 grid((lanes + bs - 1) / bs, (g.lv[l].h + kResizeRows - 1) / kResizeRows, nf);
-        hipLaunchKernelGGL(k_resize, grid, dim3(bs), 0, st, ex->d_geo, l, ex->d_pyr, g.pyrBytes, ex->d_xofs, ex->d_xcoef,
-                           ex->d_yofs, ex->d_ycoef);
+        const int groups = (g.lv[l].h + kResizeRows - 1) / kResizeRows;
+        dim3 grid((unsigned)(((long long)lanes * groups + 255) / 256), nf);
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, ex->d_geo, l, ex->d_pyr, g.pyrBytes, ex->d_xofs, ex->d_xcoef,
+                           ex->d_yofs, ex->d_ycoef, lanes, lanes == 1 ? 0xFFFFFFFFu : (uint32_t)(0x100000000ull / (unsigned)lanes));
     }
     mark(ex, st);
     if (g.tileP == 48)
