@@ -93,14 +93,20 @@ __device__ __forceinline__ int stage_pixel(const StageGeo& g, const uint8_t* __r
 
 // mode 0: grey conversion only; 1: remap; 2: resize.  One lane = 4 consecutive output pixels of a row.
 template <int CN, int MODE>
-__global__ __launch_bounds__(64) void k_stage(StageGeo g, const uint8_t* __restrict__ src, int srcRow,
-                                              long long srcFrame, uint8_t* __restrict__ dst, long long dstRow,
-                                              long long dstFrame, int dstAligned) {
-    const int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int y = blockIdx.y;
-    if (x4 >= g.dw) return;
-    const uint8_t* S = src + (long long)blockIdx.z * srcFrame;
-    uint8_t* D = dst + (long long)blockIdx.z * dstFrame + (long long)y * dstRow + x4;
+__global__ __launch_bounds__(256) void k_stage(StageGeo g, const uint8_t* __restrict__ src, int srcRow,
+                                               long long srcFrame, uint8_t* __restrict__ dst, long long dstRow,
+                                               long long dstFrame, int dstAligned, int lanesPerRow,
+                                               uint32_t lanesPerRowRcp) {
+    // (row, 4-pixel column) as one sequence: full workgroups whatever the width; lanesPerRowRcp =
+    // floor(2^32 / lanesPerRow), one correction step makes the quotient exact
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t row = __umulhi(i, lanesPerRowRcp);
+    uint32_t col = i - row * (uint32_t)lanesPerRow;
+    if (col >= (uint32_t)lanesPerRow) { ++row; col -= (uint32_t)lanesPerRow; }
+    const int y = (int)row, x4 = (int)col * 4;
+    if (y >= g.dh) return;
+    const uint8_t* S = src + (long long)blockIdx.y * srcFrame;
+    uint8_t* D = dst + (long long)blockIdx.y * dstFrame + (long long)y * dstRow + x4;
     const int n = min(4, g.dw - x4);
     int xy[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
     if constexpr (MODE == 1) {
@@ -247,9 +253,11 @@ orbx_status orbx_stage_enqueue(orbx_stager* s, const uint8_t* d_src, int n_frame
     g.xofs = static_cast<const int*>(s->d_xofs); g.xa = static_cast<const short2*>(s->d_xa);
     g.yofs = static_cast<const int*>(s->d_yofs); g.ya = static_cast<const short2*>(s->d_ya);
     const int aligned = ((((uintptr_t)d_dst) | (uintptr_t)dstRow | (uintptr_t)dstFrame) & 3) == 0;
-    const dim3 block(64), grid((p.dst_width + 4 * 64 - 1) / (4 * 64), p.dst_height, n_frames);
+    const int lanes = (p.dst_width + 3) / 4;
+    const uint32_t lanesRcp = lanes == 1 ? 0xFFFFFFFFu : (uint32_t)(0x100000000ull / (unsigned)lanes);
+    const dim3 block(256), grid((unsigned)(((long long)lanes * p.dst_height + 255) / 256), n_frames);
 #define ORBX_STAGE_LAUNCH(CN, MODE) \
-    hipLaunchKernelGGL((k_stage<CN, MODE>), grid, block, 0, st, g, d_src, (int)srcRow, srcFrame, d_dst, dstRow, dstFrame, aligned)
+    hipLaunchKernelGGL((k_stage<CN, MODE>), grid, block, 0, st, g, d_src, (int)srcRow, srcFrame, d_dst, dstRow, dstFrame, aligned, lanes, lanesRcp)
 #define ORBX_STAGE_MODE(CN)                                   \
     do {                                                      \
         if (p.mode == ORBX_STAGE_NONE) ORBX_STAGE_LAUNCH(CN, 0);       \
