@@ -741,17 +741,25 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
 
         // (2) choose the nodes to split and the creation order of their children
         int total;   // number of children created
+        int kept;    // nodes that are not split
         if (!careful) {
-            // full sweep: every node with more than one key, in list order
+            // full sweep: every node with more than one key, in list order.  One scan carries both prefix sums:
+            // children created before the node (low half) and unsplit nodes before it (high half); neither exceeds
+            // 4 x the list capacity < 65536.
             for (int p = tid; p < size; p += kQtThreads) {
-                int nc = 0;
+                int v = 1 << 16;
                 if (cnt[p] > 1)
-                    nc = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0);
-                scanv[p] = nc;
+                    v = (child[4 * p] > 0) + (child[4 * p + 1] > 0) + (child[4 * p + 2] > 0) + (child[4 * p + 3] > 0);
+                scanv[p] = v;
             }
             __syncthreads();
-            total = qt_block_scan(scanv, size, tmp);
-            for (int p = tid; p < size; p += kQtThreads) base[p] = (cnt[p] > 1) ? scanv[p] : -1;
+            const int both = qt_block_scan(scanv, size, tmp);
+            total = both & 0xFFFF; kept = both >> 16;
+            for (int p = tid; p < size; p += kQtThreads) {
+                const int v = scanv[p];
+                base[p] = (cnt[p] > 1) ? (v & 0xFFFF) : -1;
+                scanv[p] = v >> 16;      // (3) position of a node that stays, among those that stay
+            }
             __syncthreads();
         } else {
             // careful pass: sort the expandable record (all waves), split from the back until N nodes
@@ -793,9 +801,11 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
         }
 
         // (3) positions of the nodes that stay: after all children, old relative order
-        for (int p = tid; p < size; p += kQtThreads) scanv[p] = (base[p] < 0) ? 1 : 0;
-        __syncthreads();
-        const int kept = qt_block_scan(scanv, size, tmp);
+        if (careful) {
+            for (int p = tid; p < size; p += kQtThreads) scanv[p] = (base[p] < 0) ? 1 : 0;
+            __syncthreads();
+            kept = qt_block_scan(scanv, size, tmp);
+        }
         const int newSize = total + kept;
         if (newSize > cap) {   // cannot happen for a consistent geometry; never write out of bounds
             if (tid == 0) { atomicAdd(&err->kp_overflow, 1); s_bad = 1; s_done = 1; }
