@@ -1391,9 +1391,14 @@ static void free_geo_buffers(orbx_extractor* ex) {
 // Computes the level / cell / quadtree geometry for a w x h image and (re)allocates the
 // device slabs.  Called at creation for the maximum size and again when the size changes.
 static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
+    // Until the last upload below has succeeded the handle has no geometry: a failure on the way (an image too
+    // small for the FAST grid, an allocation that fails) must send the next call through here again, never
+    // to kernels launched against half-built buffers.  The geometry is built in a local and committed at the end.
+    ex->geoValid = false;
     ++ex->geoEpoch;
+    if (ex->hostGraph) { hipGraphExecDestroy(ex->hostGraph); ex->hostGraph = nullptr; }
     const orbx_params& P = ex->prm;
-    OrbxFrameGeo& g = ex->geo;
+    OrbxFrameGeo g;
     memset(&g, 0, sizeof(g));
     g.nlevels = P.nlevels; g.w = w; g.h = h;
     long long off = 0, candOff = 0;
@@ -1517,6 +1522,7 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
         ORBX_HIP_TRY(hipMemcpy(ex->d_kpLevel, kpLevel.data(), kpLevel.size(), hipMemcpyHostToDevice));
     }
     ORBX_HIP_TRY(hipMemcpy(ex->d_geo, &g, sizeof(g), hipMemcpyHostToDevice));
+    ex->geo = g;
     ex->geoValid = true;
     return ORBX_OK;
 }

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64 * kStWaves) void k_stereo_rows(const OrbxFrameGe
     const int frame = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nL = countsL[2 * frame];
+    const int nL = min(countsL[2 * frame], capacity);
     const int nRows = geo->lv[0].h;
     const float minZ = mb, minD = 0.f;
     const float maxD = __fdiv_rn(mbf, minZ);
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void k_stereo_median(const int* __restrict__ c
     __shared__ int hist[256];
     __shared__ int s_bin, s_rank, s_cnt, s_median;
     const int frame = blockIdx.x, tid = threadIdx.x;
-    const int nL = countsL[2 * frame];
+    const int nL = min(countsL[2 * frame], capacity);
     const long long base = (long long)frame * capacity;
     // pass 1: high part of the SAD (121 * 255 < 2^15)
     hist[tid] = 0;

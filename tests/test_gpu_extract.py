@@ -194,6 +194,47 @@ def test_full_hd_5000_features(oracle):
     _same(ko, do, mo, kg, dg, mg)
 
 
+def test_failed_geometry_leaves_no_stale_state(oracle):
+    # an image too small for the FAST grid is refused every time it is offered, and the handle keeps working
+    A = _gpu()
+    g = A.ORBextractor(1000, 1.2, 8, 20, 7, max_width=752, max_height=480)
+    o = oracle.Extractor(1000)
+    img = synth.scene(752, 480, 61)
+    ref = o(img, (0, 0))
+    _same(*ref, *g(img, (0, 0)))
+    small = synth.scene(100, 60, 62)
+    for _ in range(2):
+        with pytest.raises(A.OrbxError) as e:
+            g(small, (0, 0))
+        assert e.value.status == -1
+    _same(*ref, *g(img, (0, 0)))
+    other = synth.scene(640, 400, 63)
+    _same(*o(other, (0, 0)), *g(other, (0, 0)))
+
+
+def test_full_hd_batch_device(oracle):
+    # the batched 1920x1080 / 5000-feature configuration on the device-resident path: 8 distinct frames
+    # in one launch sequence, two of them checked against the oracle, all of them against the one-frame path
+    A = _gpu()
+    import torch
+    nb = 8
+    imgs = [synth.scene(1920, 1080, 400 + i, n_prims=1500) for i in range(nb)]
+    g = A.ORBextractor(5000, 1.2, 8, 20, 7, max_width=1920, max_height=1080, max_batch=nb)
+    d = torch.from_numpy(np.stack(imgs)).cuda()
+    kps, desc, counts = g.extract_batch_device(d, (0, 0))
+    torch.cuda.synchronize()
+    g.status()
+    kps, desc, counts = kps.cpu().numpy(), desc.cpu().numpy(), counts.cpu().numpy()
+    o = oracle.Extractor(5000)
+    one = A.ORBextractor(5000, 1.2, 8, 20, 7, max_width=1920, max_height=1080)
+    for f in range(nb):
+        n = int(counts[f, 0])
+        k = np.frombuffer(kps[f, :n].tobytes(), dtype=A.KP_DTYPE)
+        ref = o(imgs[f], (0, 0)) if f in (1, 6) else one(imgs[f], (0, 0))
+        assert n >= 5000
+        _same(ref[0], ref[1], ref[2], k, desc[f, :n], int(counts[f, 1]))
+
+
 def test_candidate_buffer_regrows(oracle):
     # pure noise has far more FAST corners than the default candidate capacity
     A = _gpu()
