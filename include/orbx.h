@@ -226,6 +226,17 @@ size_t orbx_knn2_workspace_bytes(int n_query, int64_t n_train);
 orbx_status orbx_hamming_knn2_device(const uint8_t* d_query, int n_query, const uint8_t* d_train, int64_t n_train,
                                      int64_t base_index, orbx_match2* d_out, void* d_workspace, size_t workspace_bytes,
                                      void* stream);
+/* orbx_hamming_knn2_device for callers that cannot allocate device memory (code under HIP graph
+ * capture, serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The
+ * per-chunk partial results live in a fixed 16 MiB array inside the library's device image (one copy
+ * per GPU, held until the process ends) instead of a caller workspace, so the call performs no
+ * hipMalloc / hipFree.  n_query is limited to orbx_knn2_static_max_queries() (1 048 576); larger
+ * inputs return ORBX_ERR_INVALID.  Results are identical to orbx_hamming_knn2_device.  All calls on
+ * one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two threads)
+ * race; order them. */
+size_t orbx_knn2_static_max_queries(void);
+orbx_status orbx_hamming_knn2_device_static(const uint8_t* d_query, int n_query, const uint8_t* d_train,
+                                            int64_t n_train, int64_t base_index, orbx_match2* d_out, void* stream);
 /* Merge n_parts per-shard results (n_parts x n_query, shard-major) into the global top-2,
  * lexicographic on (dist, idx): the step after an all-gather of per-GPU shards. */
 orbx_status orbx_knn2_merge_device(const orbx_match2* d_parts, int n_parts, int n_query, orbx_match2* d_out,

@@ -99,6 +99,9 @@ PROTOTYPES = {
     "orbx_knn2_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int64]),
     "orbx_hamming_knn2_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    "orbx_knn2_static_max_queries": (C.c_size_t, []),
+    "orbx_hamming_knn2_device_static": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                                  C.c_void_p]),
     "orbx_knn2_merge_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "orbx_stereo_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),

@@ -13,6 +13,7 @@
 #include <climits>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "orbx_common.h"
@@ -399,6 +400,74 @@ extern "C" orbx_status orbx_hamming_knn2_device(const uint8_t* d_query, int n_qu
                            (orbx_match2*)d_workspace);
     }
     hipLaunchKernelGGL(k_knn2_merge, dim3((n_query + 3) / 4), dim3(256), 0, st, (const orbx_match2*)d_workspace, chunks,
+                       n_query, d_out);
+    ORBX_HIP_TRY(hipGetLastError());
+    return ORBX_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// The same search for callers that may not allocate (stream capture, serving loops): the
+// per-chunk partial results go to a fixed array in the library's own device image instead of
+// a caller workspace.  Every GPU holds its own copy of the array; host code must never use
+// the array's name as an address, only what hipGetSymbolAddress returns on that GPU.
+// --------------------------------------------------------------------------------------
+constexpr size_t kKnnStaticBytes = (size_t)16 << 20;
+static __device__ __align__(256) unsigned char g_knnStatic[kKnnStaticBytes];
+
+namespace {
+void* g_knnStaticPtr[kMaxDevices] = {};
+std::mutex g_knnStaticMutex;
+
+// Address of the current device's copy of g_knnStatic (looked up once per device).
+orbx_status knn_static_ptr(void** out) {
+    int dev = 0;
+    ORBX_HIP_TRY(hipGetDevice(&dev));
+    ORBX_REQUIRE(dev >= 0 && dev < kMaxDevices, "device ordinal %d is beyond the %d this library tracks", dev, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_knnStaticMutex);
+    if (!g_knnStaticPtr[dev]) {
+        void* p = nullptr;
+        ORBX_HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(g_knnStatic)));
+        ORBX_REQUIRE(p != nullptr, "hipGetSymbolAddress returned a null address");
+        g_knnStaticPtr[dev] = p;
+    }
+    *out = g_knnStaticPtr[dev];
+    return ORBX_OK;
+}
+}  // namespace
+
+extern "C" size_t orbx_knn2_static_max_queries(void) { return kKnnStaticBytes / sizeof(orbx_match2); }
+
+extern "C" orbx_status orbx_hamming_knn2_device_static(const uint8_t* d_query, int n_query, const uint8_t* d_train,
+                                                       int64_t n_train, int64_t base_index, orbx_match2* d_out,
+                                                       void* stream) {
+    ORBX_REQUIRE(n_query >= 0 && n_train >= 0, "negative size");
+    if (n_query == 0) return ORBX_OK;
+    ORBX_REQUIRE(d_query && d_out && (n_train == 0 || d_train), "null argument");
+    ORBX_REQUIRE(base_index >= 0 && base_index + n_train <= (int64_t)INT_MAX, "train index does not fit 32 bits");
+    ORBX_REQUIRE((((uintptr_t)d_query | (uintptr_t)d_train) & 15) == 0, "descriptor arrays must be 16-byte aligned");
+    const size_t perChunk = (size_t)n_query * sizeof(orbx_match2);
+    ORBX_REQUIRE(perChunk <= kKnnStaticBytes,
+                 "%d queries exceed the %zu the allocation-free search supports (its partial results live in a fixed "
+                 "%zu-byte device array); use orbx_hamming_knn2_device with a workspace",
+                 n_query, kKnnStaticBytes / sizeof(orbx_match2), kKnnStaticBytes);
+    void* scratch = nullptr;
+    orbx_status s = knn_static_ptr(&scratch);
+    if (s != ORBX_OK) return s;
+    hipStream_t st = (hipStream_t)stream;
+    // as many chunks as the workspace variant would use, capped by what the array holds; the merge is
+    // lexicographic on (distance, index), so the result does not depend on the number of chunks
+    int chunks = 0;
+    if (n_train > 0) chunks = (int)std::min<size_t>((size_t)knn2_chunks(n_query, n_train), kKnnStaticBytes / perChunk);
+    if (chunks > 0) {
+        const long long chunkLen = (n_train + chunks - 1) / chunks;
+        const int groups = (n_query + 64 * kQpl - 1) / (64 * kQpl);
+        dim3 grid((groups + kKnnWaves - 1) / kKnnWaves, chunks);
+        hipLaunchKernelGGL(k_knn2, grid, dim3(64 * kKnnWaves), 0, st, (const uint32_t*)d_query, n_query,
+                           (const uint32_t*)d_train, (long long)n_train, chunkLen, (long long)base_index,
+                           (orbx_match2*)scratch);
+    }
+    // every partial the merge reads was written by the launch above: nothing in the array has to start at zero
+    hipLaunchKernelGGL(k_knn2_merge, dim3((n_query + 3) / 4), dim3(256), 0, st, (const orbx_match2*)scratch, chunks,
                        n_query, d_out);
     ORBX_HIP_TRY(hipGetLastError());
     return ORBX_OK;

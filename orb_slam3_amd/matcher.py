@@ -399,6 +399,17 @@ def knn_match2_device(d_query, d_train, base_index: int = 0, out=None, workspace
     return out, workspace
 
 
+def knn_match2_device_static(d_query, d_train, out, base_index: int = 0):
+    """orbx_hamming_knn2_device_static: the same search with its partial results in the library's
+    fixed device array; `out` (int32 [nq,4] CUDA tensor) is the caller's, nothing is allocated."""
+    import torch
+    nq, nt = d_query.shape[0], d_train.shape[0]
+    st = torch.cuda.current_stream(d_query.device).cuda_stream
+    check(lib().orbx_hamming_knn2_device_static(d_query.data_ptr(), nq, d_train.data_ptr(), nt, base_index,
+                                                out.data_ptr(), st))
+    return out
+
+
 def knn2_merge_device(d_parts, out=None):
     """d_parts: int32 CUDA tensor [n_parts, nq, 4] (e.g. all-gathered per-GPU shard results)."""
     import torch
