@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liborbx.so")
+# ORBX_LIB points the loader at another build of the same library (the diagnostic build with phase stamps)
+LIB_PATH = os.environ.get("ORBX_LIB") or os.path.join(_HERE, "lib", "liborbx.so")
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])

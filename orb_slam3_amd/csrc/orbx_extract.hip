@@ -229,43 +229,59 @@ __device__ __forceinline__ us2 pk_min(us2 a, us2 b) { return __builtin_elementwi
 __device__ __forceinline__ us2 pk_swap(us2 a) { return __builtin_shufflevector(a, a, 1, 0); }
 
 // Arc strength of the pixel at (x, y): with p[k] the 16 circle pixels and v the centre,
-//   strength = max( v - min_arcs(max of 9 contiguous p),  max_arcs(min of 9 contiguous p) - v )
-// which equals max over the 16 arcs of max(min(v - p), -max(v - p)) (cornerScore<16> before its
-// "- 1").  Sliding max / min by doubling (2, 4, 8, then 9) on packed 16-bit pairs: register k
-// holds (p[k], p[k+8]), so one packed op advances arcs k and k+8 together; the second half of
-// the cyclic sequence is the same registers with their halves swapped.
-__device__ __forceinline__ int fast_strength_lds(const uint8_t* t, int P, int x, int y) {
+//   bright strength = max over the 16 arcs of 9 contiguous pixels of min(p) - v
+//   dark strength   = v - min over the arcs of max(p)  =  the bright strength of the inverted values 255 - p, 255 - v
+// and cornerScore<16> before its "- 1" is the larger of the two.  Only strengths above `floorTh` matter to the
+// caller (anything else is "no corner"), and an arc of 9 contains one pixel of every antipodal pair, so a polarity
+// can exceed floorTh only if one of p0 / p8 and one of p4 / p12 differ from the centre by more than floorTh in its
+// direction.  That test picks the polarity to evaluate (the inversion makes one code path serve both); a pixel
+// that passes for both polarities (about one survivor of the quick reject in 300) is evaluated twice, one that
+// passes for neither returns 0.
+// Sliding min by doubling (2, 4, 8, then 9) on packed 16-bit pairs: register k holds (p[k], p[k+8]), so one packed
+// op advances arcs k and k+8 together; the second half of the cyclic sequence is the same registers with their halves
+// swapped.
+__device__ __forceinline__ int fast_arc_min_max(const us2 (&P8)[8], uint32_t inv) {
+    us2 E[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) E[k] = __builtin_bit_cast(us2, __builtin_bit_cast(uint32_t, P8[k]) ^ inv);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) E[8 + k] = pk_swap(E[k]);
+    us2 lo2[10], lo4[12];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lo2[k] = pk_min(E[k], E[k + 1]);
+    lo2[8] = pk_swap(lo2[0]); lo2[9] = pk_swap(lo2[1]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lo4[k] = pk_min(lo2[k], lo2[k + 2]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lo4[8 + k] = pk_swap(lo4[k]);
+    us2 B = us2{0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const us2 lo9 = pk_min(pk_min(lo4[k], lo4[k + 4]), E[k + 8]);   // min of p[k .. k+8] | p[k+8 .. k+16]
+        B = pk_max(B, lo9);
+    }
+    return max((int)B.x, (int)B.y);
+}
+
+__device__ __forceinline__ int fast_strength_lds(const uint8_t* t, int P, int x, int y, int floorTh) {
     // addressed from the top-left corner of the 7x7 neighbourhood: every offset is non-negative
     // (an immediate when the pitch is a compile-time constant)
     const uint8_t* c = t + (y - 3) * P + (x - 3);
 #define ORBX_PX(dx, dy) c[(3 + (dy)) * P + 3 + (dx)]
     const int v = ORBX_PX(0, 0);
-    us2 E[16];
+    us2 E[8];
     E[0] = us2{ORBX_PX(0, 3), ORBX_PX(0, -3)};     E[1] = us2{ORBX_PX(1, 3), ORBX_PX(-1, -3)};
     E[2] = us2{ORBX_PX(2, 2), ORBX_PX(-2, -2)};    E[3] = us2{ORBX_PX(3, 1), ORBX_PX(-3, -1)};
     E[4] = us2{ORBX_PX(3, 0), ORBX_PX(-3, 0)};     E[5] = us2{ORBX_PX(3, -1), ORBX_PX(-3, 1)};
     E[6] = us2{ORBX_PX(2, -2), ORBX_PX(-2, 2)};    E[7] = us2{ORBX_PX(1, -3), ORBX_PX(-1, 3)};
 #undef ORBX_PX
-#pragma unroll
-    for (int k = 0; k < 8; ++k) E[8 + k] = pk_swap(E[k]);
-    us2 hi2[10], lo2[10], hi4[12], lo4[12];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { hi2[k] = pk_max(E[k], E[k + 1]); lo2[k] = pk_min(E[k], E[k + 1]); }
-    hi2[8] = pk_swap(hi2[0]); hi2[9] = pk_swap(hi2[1]); lo2[8] = pk_swap(lo2[0]); lo2[9] = pk_swap(lo2[1]);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { hi4[k] = pk_max(hi2[k], hi2[k + 2]); lo4[k] = pk_min(lo2[k], lo2[k + 2]); }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { hi4[8 + k] = pk_swap(hi4[k]); lo4[8 + k] = pk_swap(lo4[k]); }
-    us2 A = us2{65535, 65535}, B = us2{0, 0};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const us2 hi9 = pk_max(pk_max(hi4[k], hi4[k + 4]), E[k + 8]);   // max of p[k .. k+8] | p[k+8 .. k+16]
-        const us2 lo9 = pk_min(pk_min(lo4[k], lo4[k + 4]), E[k + 8]);
-        A = pk_min(A, hi9);
-        B = pk_max(B, lo9);
-    }
-    const int a = min((int)A.x, (int)A.y), bb = max((int)B.x, (int)B.y);
-    return max(v - a, bb - v);
+    const int hiV = max((int)E[0].x, (int)E[0].y), hiH = max((int)E[4].x, (int)E[4].y);
+    const int loV = min((int)E[0].x, (int)E[0].y), loH = min((int)E[4].x, (int)E[4].y);
+    const bool bright = min(hiV, hiH) - v > floorTh, dark = v - max(loV, loH) > floorTh;
+    int st = 0;
+    if (bright || dark) st = fast_arc_min_max(E, bright ? 0u : 0x00FF00FFu) - (bright ? v : 255 - v);
+    if (bright && dark) st = max(st, fast_arc_min_max(E, 0x00FF00FFu) - (255 - v));
+    return st;
 }
 
 __device__ __forceinline__ int score_at(int strength, int th) { return strength > th ? strength - 1 : 0; }
@@ -281,6 +297,71 @@ __device__ __forceinline__ bool in_any_rect(float X, float Y, const orbx_rect* r
 }
 
 constexpr int kFastThreads = 128;
+
+// Diagnostic build only (-DORBX_FAST_STAMPS, tools/prof_fast_phases.py): wave 0 of every workgroup adds the shader
+// cycles it spent between the phase boundaries of k_fast to a device array; the product library contains none of it.
+#ifdef ORBX_FAST_STAMPS
+constexpr int kStampWgs = 1 << 18;
+__device__ unsigned int g_fastStamps[kStampWgs][6];     // per workgroup: 5 phase durations + a "ran" mark
+#define ORBX_STAMP(slot)                                                                   \
+    do {                                                                                   \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();                     \
+        if (threadIdx.x == 0 && stampWg < kStampWgs) g_fastStamps[stampWg][slot] = (unsigned int)(now__ - stampPrev); \
+        stampPrev = now__;                                                                 \
+    } while (0)
+#define ORBX_STAMP_BEGIN()                                                                 \
+    const int stampWg = blockIdx.y * gridDim.x + blockIdx.x;                               \
+    if (threadIdx.x == 0 && stampWg < kStampWgs) g_fastStamps[stampWg][5] = 1u;            \
+    unsigned long long stampPrev = __builtin_amdgcn_s_memtime()
+// Sums over the workgroups that ran since the last reset: out8[0..4] = cycles per phase, out8[7] = workgroups.
+extern "C" int orbx_debug_fast_stamps(unsigned long long* out8, int reset) {
+    std::vector<unsigned int> h((size_t)kStampWgs * 6);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_fastStamps), h.size() * 4) != hipSuccess) return -1;
+    for (int k = 0; k < 8; ++k) out8[k] = 0;
+    for (int w = 0; w < kStampWgs; ++w) {
+        if (!h[(size_t)w * 6 + 5]) continue;
+        for (int k = 0; k < 5; ++k) out8[k] += h[(size_t)w * 6 + k];
+        ++out8[7];
+    }
+    if (reset) {
+        std::fill(h.begin(), h.end(), 0u);
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fastStamps), h.data(), h.size() * 4) != hipSuccess) return -1;
+    }
+    return 0;
+}
+// k_describe: per wave
+__device__ unsigned int g_descStamps[kStampWgs][6];
+#define ORBX_DSTAMP(slot)                                                                  \
+    do {                                                                                   \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();                     \
+        if (lane == 0 && dstampId < kStampWgs) g_descStamps[dstampId][slot] = (unsigned int)(now__ - dstampPrev); \
+        dstampPrev = now__;                                                                \
+    } while (0)
+#define ORBX_DSTAMP_BEGIN()                                                                \
+    const int dstampId = (blockIdx.y * gridDim.x + blockIdx.x) * kDescWaves + wv;          \
+    if (lane == 0 && dstampId < kStampWgs) g_descStamps[dstampId][5] = active ? 1u : 0u;   \
+    unsigned long long dstampPrev = __builtin_amdgcn_s_memtime()
+extern "C" int orbx_debug_desc_stamps(unsigned long long* out8, int reset) {
+    std::vector<unsigned int> h((size_t)kStampWgs * 6);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_descStamps), h.size() * 4) != hipSuccess) return -1;
+    for (int k = 0; k < 8; ++k) out8[k] = 0;
+    for (int w = 0; w < kStampWgs; ++w) {
+        if (!h[(size_t)w * 6 + 5]) continue;
+        for (int k = 0; k < 5; ++k) out8[k] += h[(size_t)w * 6 + k];
+        ++out8[7];
+    }
+    if (reset) {
+        std::fill(h.begin(), h.end(), 0u);
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_descStamps), h.data(), h.size() * 4) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define ORBX_STAMP(slot) do {} while (0)
+#define ORBX_STAMP_BEGIN() do {} while (0)
+#define ORBX_DSTAMP(slot) do {} while (0)
+#define ORBX_DSTAMP_BEGIN() do {} while (0)
+#endif
 
 // kP = LDS tile pitch known at compile time (row steps and the 3-row look-ahead become
 // immediate offsets), or 0 to take it from the geometry.
@@ -320,6 +401,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     const int xa = x0 & ~3, ox = x0 - xa;
     const int rowDwords = (x0 + tw - xa + 3) >> 2;      // <= P / 4
 
+    ORBX_STAMP_BEGIN();
     if (tid == 0) { s_nQueue = 0; s_nIni = 0; s_nMin = 0; s_nKeep = 0; }
     const uint8_t* img = pyr + (long long)frame * frameStride + G.off;
     {
@@ -364,6 +446,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
         }
     }
     __syncthreads();
+    ORBX_STAMP(0);   // tile load
 
     const int iw = tw - 6, ih = th - 6;   // pixels FAST can test
     const int lowTh = min(iniTh, minTh);
@@ -376,6 +459,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
         // Four pixels (one tile dword) per lane and step, compared byte-wise with v_lerp_u8:
         //   lerp(a, ~b, c) = (a - b + 255 + c) >> 1 per byte, so with c chosen to make t + 256 + c even
         //   "a - b > t"  <=>  lerp(a, ~b, c) >= K := (t + 256 + c) / 2  <=>  bit 7 of lerp(lerp(a, ~b, c), ~K, 1).
+        // Three lerps per neighbour: the half-difference, its test against K (brighter) and against Z (darker).
         // The testable pixels are cut into horizontal bands; a lane walks down one dword column of one
         // band with that column's 7 rows (y-3 .. y+3) in registers, so each further 4 pixels cost three
         // LDS dword reads.  One wave does the whole cell (fewer instructions than two waves with
@@ -386,6 +470,12 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
             // K = 256 (threshold 255: nothing can pass) is clamped; the few extra survivors are rejected by (B)
             const uint32_t K = min((uint32_t)((t1 + 255 + (cRound & 1u)) >> 1), 255u);
             const uint32_t nK = ~(K * 0x01010101u);
+            // The same half-difference h = (neighbour - centre + 255 + c) >> 1 answers the dark side: centre -
+            // neighbour >= t1 means neighbour - centre + 255 + c <= Z := 255 + c - t1, which implies h <= Z >> 1,
+            // i.e. NOT h >= (Z >> 1) + 1.  (The converse fails for one value of the difference: a few more
+            // survivors, which (B) rejects.)
+            const int Z = 255 + (int)(cRound & 1u) - t1;
+            const uint32_t nZ = ~((uint32_t)((Z >> 1) + 1) * 0x01010101u);
             const int dFirst = (ox + 3) >> 2, dLast = (ox + 3 + iw - 1) >> 2;     // tile dword columns with testable pixels
             const int ncol = dLast - dFirst + 1;
             const int bands = max(1, min(64 / ncol, ih));
@@ -413,15 +503,16 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
                     const uint32_t C = a3, nC = ~C;                                                         \
                     const uint32_t Lw = __builtin_amdgcn_alignbyte(C, c[-1], 1);   /* pixels x - 3 */       \
                     const uint32_t Rw = __builtin_amdgcn_alignbyte(c[1], C, 3);    /* pixels x + 3 */       \
-                    const uint32_t bU = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(a0, nC, cRound), nK, 0x01010101u); \
-                    const uint32_t bD = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(a6, nC, cRound), nK, 0x01010101u); \
-                    const uint32_t bL = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(Lw, nC, cRound), nK, 0x01010101u); \
-                    const uint32_t bR = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(Rw, nC, cRound), nK, 0x01010101u); \
-                    const uint32_t dU = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(C, ~a0, cRound), nK, 0x01010101u); \
-                    const uint32_t dD = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(C, ~a6, cRound), nK, 0x01010101u); \
-                    const uint32_t dL = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(C, ~Lw, cRound), nK, 0x01010101u); \
-                    const uint32_t dR = __builtin_amdgcn_lerp(__builtin_amdgcn_lerp(C, ~Rw, cRound), nK, 0x01010101u); \
-                    const uint32_t F = (((bU | bD) & (bL | bR)) | ((dU | dD) & (dL | dR))) & valid;        \
+                    /* per byte (neighbour - centre + 255 + c) >> 1: one value serves both polarities */    \
+                    const uint32_t hU = __builtin_amdgcn_lerp(a0, nC, cRound), hD = __builtin_amdgcn_lerp(a6, nC, cRound); \
+                    const uint32_t hL = __builtin_amdgcn_lerp(Lw, nC, cRound), hR = __builtin_amdgcn_lerp(Rw, nC, cRound); \
+                    /* bit 7: neighbour brighter than the centre by more than the threshold */              \
+                    const uint32_t bU = __builtin_amdgcn_lerp(hU, nK, 0x01010101u), bD = __builtin_amdgcn_lerp(hD, nK, 0x01010101u); \
+                    const uint32_t bL = __builtin_amdgcn_lerp(hL, nK, 0x01010101u), bR = __builtin_amdgcn_lerp(hR, nK, 0x01010101u); \
+                    /* bit 7 clear: neighbour darker than the centre by more than the threshold (or by exactly it) */ \
+                    const uint32_t eU = __builtin_amdgcn_lerp(hU, nZ, 0x01010101u), eD = __builtin_amdgcn_lerp(hD, nZ, 0x01010101u); \
+                    const uint32_t eL = __builtin_amdgcn_lerp(hL, nZ, 0x01010101u), eR = __builtin_amdgcn_lerp(hR, nZ, 0x01010101u); \
+                    const uint32_t F = (((bU | bD) & (bL | bR)) | ~((eU & eD) | (eL & eR))) & valid;        \
                     /* the four flag bits (7, 15, 23, 31) gathered into one nibble */                       \
                     mask = (mask << 4) | (((F >> 7) * 0x00204081u) >> 21 & 15u);                            \
                     c += PD;                                                                                \
@@ -454,6 +545,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
         }
     }
     __syncthreads();
+    ORBX_STAMP(1);   // quick reject
     const int nQueue = s_nQueue;
     const int lane = tid & 63, waveBase = tid & ~63;
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
@@ -469,7 +561,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
         if (q < nQueue) {
             rec = s_queue[q];
             const int x = rec & 127, y = rec >> 7;
-            const int st = fast_strength_lds(T, P, x, y);
+            const int st = fast_strength_lds(T, P, x, y, lowTh);
             corner = st > lowTh;
             if (corner) S[y * P + x] = (uint8_t)st;      // the strength tile was cleared by the tile load
         }
@@ -481,6 +573,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
         nMine += __popcll(bal);
     }
     __syncthreads();
+    ORBX_STAMP(2);   // arc strength + compaction
     // (C) 3x3 non-maximum suppression of the corners at both thresholds.  The image tile is no longer needed:
     // it receives the list of corners kept at either threshold, (verdicts << 14) | position.
     unsigned short* s_keep = reinterpret_cast<unsigned short*>(tile);
@@ -522,6 +615,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
         }
     }
     __syncthreads();
+    ORBX_STAMP(3);   // non-maximum suppression
     const bool useIni = s_nIni > 0;
     const int n = useIni ? s_nIni : s_nMin;
     if (n == 0) return;
@@ -576,6 +670,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
             atomicMax(&err->need_cand, pos + 1);
         }
     }
+    ORBX_STAMP(4);   // round trip + emission
 }
 
 // ======================================================================================
@@ -991,6 +1086,8 @@ __global__ __launch_bounds__(kLayThreads) void k_layout(const OrbxFrameGeo* __re
 constexpr int kDescWaves = 4;
 constexpr int kRawR = 21, kRawW = 43, kRawP = 48;   // raw rows start at a 4-byte aligned column (at most 3 + 43 bytes)
 constexpr int kBlurR = 18, kBlurW = 37, kBlurP = 40;
+// transposed row sums: one dword = the sums of a row pair; an odd pitch (in dwords) spreads the columns over the banks
+constexpr int kHorTPD = 23;
 
 __device__ __forceinline__ int reflect101_dev(int p, int n) {
     if (n == 1) return 0;
@@ -1085,9 +1182,10 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
                                                               const uint8_t* __restrict__ kpLevel) {
     // Per wave: the raw patch (later the blurred core) and the transposed row sums.  Nothing is shared between the
     // waves of a workgroup, and the kernel's speed follows the number of resident waves, i.e. this footprint
-    // (5.6 KB per keypoint: 7 workgroups per CU).
-    __shared__ __align__(16) uint8_t s_raw[kDescWaves][kRawW * kRawP + 16];   // + the dword the last row's window may touch
-    __shared__ __align__(16) uint16_t s_hor[kDescWaves][40 * 44];     // transposed row sums: 40 columns x 44 rows
+    // (5.5 KB per keypoint: 7 workgroups per CU).
+    // (+ one row: the horizontal pass works on row pairs and the last pair's second row is read, never used)
+    __shared__ __align__(16) uint8_t s_raw[kDescWaves][(kRawW + 1) * kRawP + 16];   // + the dword the last row's window may touch
+    __shared__ __align__(16) uint32_t s_hor[kDescWaves][kBlurW * kHorTPD];   // transposed row sums: 37 columns x 22 row pairs
 
     // keypoints of one frame read the same few level images: keep a frame on one XCD
     const int logicalBlock = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
@@ -1110,9 +1208,10 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     active = active && kp.slot >= 0 && kp.slot < capacity;
     const uint8_t* img = pyr + (long long)frame * frameStride + G.off;
     const int cx = __float2int_rn(kp.x), cy = __float2int_rn(kp.y);
+    ORBX_DSTAMP_BEGIN();
 
     uint8_t* rawBase = s_raw[wv];
-    uint16_t* hor = s_hor[wv];
+    uint32_t* hor = s_hor[wv];
     uint8_t* blur = rawBase;   // the raw patch is dead once the horizontal pass is done
 
     // Patch rows cy-21 .. cy+21, columns cx-21 .. cx+21.  Interior keypoints fetch each row as three 16-byte
@@ -1149,6 +1248,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
+    ORBX_DSTAMP(0);   // patch load
 
     // ---- orientation: m10 = sum u*I, m01 = sum v*I over the radius-15 disc ----
     // item = (row v, group of 4 columns u0..u0+3, u0 = 4g - 15): the 4 pixels come as one byte
@@ -1177,45 +1277,50 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
         m01 += __shfl_xor(m01, off);
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
+    ORBX_DSTAMP(1);   // orientation
 
     // ---- separable 7-tap blur of the 37x37 core with the dot-product instructions ----
-    // horizontal: item = (raw row r, 8 output columns c0..c0+7).  The 14 source bytes are
-    // fetched as 5 aligned dwords and shifted into a 16-byte window (the patch starts `ox`
-    // bytes into the row); every output is two v_dot4_u32_u8 over byte windows of it.
-    // The row sums are stored TRANSPOSED (horT[c][r]) so that the vertical pass reads
-    // consecutive rows as packed 16-bit pairs.
-    constexpr int kHorTP = 44;                       // rows per column of horT (even)
+    // horizontal: item = (pair of raw rows 2 rp, 2 rp + 1; 8 output columns c0..c0+7).  The 14 source bytes of a row
+    // are fetched as two 8-byte reads and one dword (the patch starts `ox` < 4 bytes into the row, so the reads are
+    // 8-byte aligned) and shifted into a 16-byte window; every output is two v_dot4_u32_u8 over byte windows of it.
+    // The row sums are stored TRANSPOSED, horT[c][rp] = (sum of row 2 rp) | (sum of row 2 rp + 1) << 16, so that the
+    // vertical pass reads consecutive rows as packed 16-bit pairs; one dword store per column and row pair.
     const uint32_t wLo = 18u | (34u << 8) | (48u << 16) | (56u << 24);
     const uint32_t wHi = 48u | (34u << 8) | (18u << 16);
-    // All 8 outputs of an item are stored (columns 37..39 and rows 37..39 are padding that nothing
-    // reads), so the stores are unconditional and their addresses differ by compile-time constants.
-    for (int i = lane; active && i < kRawW * 5; i += 64) {
-        const int r = i / 5, c0 = (i - r * 5) * 8;
-        const int b0 = ox + c0;
-        const uint32_t* rowp = reinterpret_cast<const uint32_t*>(rawBase + r * kRawP) + (b0 >> 2);
-        const uint32_t d0 = rowp[0], d1 = rowp[1], d2 = rowp[2], d3 = rowp[3], d4 = rowp[4];
-        const int sh = b0 & 3;
-        uint32_t W[4];
-        W[0] = __builtin_amdgcn_alignbyte(d1, d0, sh); W[1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        W[2] = __builtin_amdgcn_alignbyte(d3, d2, sh); W[3] = __builtin_amdgcn_alignbyte(d4, d3, sh);
-        // byte windows A[k] = bytes k .. k+3 of the 16-byte window, k = 0 .. 11
-        uint32_t A[12];
+    constexpr int kRowPairs = (kRawW + 1) / 2;       // 22
+    for (int i = lane; active && i < kRowPairs * 5; i += 64) {
+        const int rp = i / 5, j = i - rp * 5, c0 = 8 * j;
+        uint32_t sums[2][8];
 #pragma unroll
-        for (int k = 0; k < 12; ++k)
-            A[k] = (k & 3) ? __builtin_amdgcn_alignbyte(W[(k >> 2) + 1], W[k >> 2], k & 3) : W[k >> 2];
-        uint32_t lo[8];
+        for (int h = 0; h < 2; ++h) {
+            const uint8_t* rowb = rawBase + (2 * rp + h) * kRawP + c0;     // 8-byte aligned
+            const uint2 q0 = *reinterpret_cast<const uint2*>(rowb), q1 = *reinterpret_cast<const uint2*>(rowb + 8);
+            const uint32_t d4 = *reinterpret_cast<const uint32_t*>(rowb + 16);
+            uint32_t W[4];
+            W[0] = __builtin_amdgcn_alignbyte(q0.y, q0.x, ox); W[1] = __builtin_amdgcn_alignbyte(q1.x, q0.y, ox);
+            W[2] = __builtin_amdgcn_alignbyte(q1.y, q1.x, ox); W[3] = __builtin_amdgcn_alignbyte(d4, q1.y, ox);
+            // byte windows A[k] = bytes k .. k+3 of the 16-byte window, k = 0 .. 11
+            uint32_t A[12];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) lo[k] = __builtin_amdgcn_udot4(A[k], wLo, 0u, false);
-        uint16_t* dst = hor + c0 * kHorTP + r;
+            for (int k = 0; k < 12; ++k)
+                A[k] = (k & 3) ? __builtin_amdgcn_alignbyte(W[(k >> 2) + 1], W[k >> 2], k & 3) : W[k >> 2];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dst[k * kHorTP] = (uint16_t)__builtin_amdgcn_udot4(A[k + 4], wHi, lo[k], false);
+            for (int k = 0; k < 8; ++k)
+                sums[h][k] = __builtin_amdgcn_udot4(A[k + 4], wHi, __builtin_amdgcn_udot4(A[k], wLo, 0u, false), false);
+        }
+        uint32_t* dst = hor + c0 * kHorTPD + rp;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (c0 + k < kBlurW) dst[k * kHorTPD] = sums[0][k] | (sums[1][k] << 16);     // a row sum is < 65536
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
+    ORBX_DSTAMP(2);   // horizontal blur
     // vertical: item = (column c, 8 output rows r0..r0+7): 14 row sums = 7 packed pairs, four
-    // v_dot2_u32_u16 per output; odd rows use the weight pairs shifted by one tap.
+    // v_dot2_u32_u16 per output; odd rows use the weight pairs shifted by one tap.  The blurred core is stored
+    // transposed as well, blurT[c][r]: an item's 8 outputs are 8 consecutive bytes, one 8-byte store.
     for (int i = lane; active && i < kBlurW * 5; i += 64) {
         const int seg = i / kBlurW, c = i - seg * kBlurW, r0 = seg * 8;
-        const uint32_t* colp = reinterpret_cast<const uint32_t*>(hor + c * kHorTP + r0);
+        const uint32_t* colp = hor + c * kHorTPD + (r0 >> 1);
         us2 Hh[7];
 #pragma unroll
         for (int m = 0; m < 7; ++m) Hh[m] = __builtin_bit_cast(us2, colp[m]);
@@ -1230,11 +1335,14 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
         for (int k = 0; k < 8; ++k) sum[k] = __builtin_amdgcn_udot2(Hh[(k >> 1) + 2], (k & 1) ? o2 : e2, sum[k], false);
 #pragma unroll
         for (int k = 0; k < 8; ++k) sum[k] = __builtin_amdgcn_udot2(Hh[(k >> 1) + 3], (k & 1) ? o3 : e3, sum[k], false);
-        uint8_t* dst = blur + r0 * kBlurP + c;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) dst[k * kBlurP] = (uint8_t)(sum[k] >> 16);
+        // bytes 2 of the eight sums (sum >> 16 < 256), packed four to a dword
+        uint2 out8;
+        out8.x = __builtin_amdgcn_perm(sum[1], sum[0], 0x0c0c0602u) | __builtin_amdgcn_perm(sum[3], sum[2], 0x06020c0cu);
+        out8.y = __builtin_amdgcn_perm(sum[5], sum[4], 0x0c0c0602u) | __builtin_amdgcn_perm(sum[7], sum[6], 0x06020c0cu);
+        *reinterpret_cast<uint2*>(blur + c * kBlurP + r0) = out8;    // rows 37..39 of a column are padding
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
+    ORBX_DSTAMP(3);   // vertical blur
 
     if (!active) return;
     // ---- steered BRIEF: lane handles comparisons 4*lane .. 4*lane+3 ----
@@ -1254,7 +1362,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
             const float px = (float)(int)(signed char)(w & 255u), py = (float)(int)(signed char)((w >> 8) & 255u);
             const int ry = __float2int_rn(__fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a)));
             const int rx = __float2int_rn(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b)));
-            t[e] = blur[(kBlurR + ry) * kBlurP + kBlurR + rx];
+            t[e] = blur[(kBlurR + rx) * kBlurP + kBlurR + ry];     // transposed core
         }
         nib |= (uint32_t)(t[0] < t[1]) << j;
     }
@@ -1272,6 +1380,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
         k.class_id = -1;
         outKps[row] = k;
     }
+    ORBX_DSTAMP(4);   // steered tests + output
 }
 
 // ======================================================================================

@@ -366,10 +366,25 @@ __global__ __launch_bounds__(256) void k_knn2_merge(const orbx_match2* __restric
     }
 }
 
+// Workgroups the current device keeps resident at 8 waves per SIMD (k_knn2 needs < 64 VGPRs): compute units x 8.
+static int knn2_resident_blocks() {
+    static int cached[kMaxDevices] = {};
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 2048;
+    if (!cached[dev]) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cached[dev] = cus * 32 / kKnnWaves;
+    }
+    return cached[dev];
+}
+
 static int knn2_chunks(int nq, long long nt) {
     const int groups = (nq + 64 * kQpl - 1) / (64 * kQpl);
-    // aim for >= 8192 waves on the chip, at least 256 train rows per chunk
-    long long want = (8192 + groups - 1) / std::max(groups, 1);
+    const int blocksPerChunk = (groups + kKnnWaves - 1) / kKnnWaves;
+    // One resident round: as many chunks as fill the chip once and no more.  A grid a few workgroups larger than
+    // what fits at once leaves those to run alone after everything else has finished (2050 workgroups on 2048
+    // slots cost a quarter of the search time); at least 256 train rows per chunk.
+    long long want = std::max(1, knn2_resident_blocks() / std::max(blocksPerChunk, 1));
     long long maxByLen = std::max<long long>(1, nt / 256);
     long long c = std::max<long long>(1, std::min(want, maxByLen));
     return (int)std::min<long long>(c, 4096);
