@@ -426,6 +426,39 @@ orbx_status orbx_frame_fuse_search(const orbx_frame* frame, const orbx_query* qu
                                    int n_query, const float* inv_level_sigma2, int n_levels, int* match_out,
                                    int* n_matches);
 
+/* ---- frames with a second camera (Frame::Nleft != -1: fisheye stereo) -----------------------
+ * Such a Frame keeps the left keypoints in mvKeys / mGrid, the right ones in mvKeysRight / mGridRight, and indexes
+ * mvpMapPoints / mDescriptors with left keypoints first and right keypoints at Nleft + i (Frame.cc:1265-1283).
+ * Here each camera is an orbx_frame of its own (assigned without uright: the rectified-stereo gate does not apply,
+ * ORBmatcher.cc:92); `taken` and `kp_query` run over the combined index (n_left + n_right entries).
+ * `right` may be NULL (one camera).
+ *
+ * SearchByProjection(Frame&, const vector<MapPoint*>&, th, ...) with both passes (ORBmatcher.cc:42-216).
+ * queries_left[q]: projection into the left image, radius = RadiusByViewingCos * th * scale[level],
+ * min_level / max_level = level - 1 / level; radius <= 0 = not in the left view (mbTrackInView false).
+ * queries_right[q]: the same for the right image with radius = RadiusByViewingCos * scale[level] (no th, :151-154);
+ * radius <= 0 = mbTrackInViewR false or level -1.  left_to_right / right_to_left = mvLeftToRightMatch /
+ * mvRightToLeftMatch (-1 none; may be NULL): an accepted keypoint hands the map point to its stereo partner too.
+ * query_marks[q] != 0: the map point has observations (only then do later queries skip a keypoint it occupies,
+ * :88-90); NULL = all 1.  kp_query[idx] = the last query assigned to keypoint idx (-1 none); *n_matches = the
+ * reference's return value. */
+orbx_status orbx_frame_search_by_projection_stereo(const orbx_frame* left, const orbx_frame* right,
+                                                   const orbx_query* queries_left, const orbx_query* queries_right,
+                                                   const uint8_t* query_desc, int n_query, float nn_ratio,
+                                                   const int* left_to_right, const int* right_to_left,
+                                                   uint8_t* taken, const uint8_t* query_marks, int* kp_query, int* n_matches);
+
+/* SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) with the right-image pass and the rotation histogram
+ * shared by both passes (ORBmatcher.cc:1761-1972).  queries_left[q].radius <= 0 = the map point is skipped before
+ * either pass (:1795-1803); a point whose left window holds no keypoint skips the right pass as well (:1820-1821).
+ * Accept per pass: best <= max_dist (TH_HIGH = 100 in the reference).  With query_angle the matches of the
+ * non-dominant rotation bins are removed afterwards (kp_query[idx] = -1, counted down). */
+orbx_status orbx_frame_search_window_best_stereo(const orbx_frame* left, const orbx_frame* right,
+                                                 const orbx_query* queries_left, const orbx_query* queries_right,
+                                                 const uint8_t* query_desc, int n_query, float max_dist,
+                                                 uint8_t* taken, const uint8_t* query_marks, const float* query_angle,
+                                                 float rot_factor, int* kp_query, int* n_matches);
+
 /* All Hamming distances between the entries of the same vocabulary node of two feature vectors
  * (the inner loops of SearchByBoW / SearchForTriangulation, ORBmatcher.cc:273-363, :856-907,
  * :1030-1078).  Buckets are CSR: entries off[b] .. off[b+1] of idx1 / idx2 are descriptor rows.
@@ -477,6 +510,41 @@ orbx_status orbx_search_for_triangulation(const orbx_keypoint* kps1, const uint8
                                           const float* uright2, int n2, const int* idx2, const int* off2, int n_buckets,
                                           const orbx_epipolar* geom, int only_stereo, int coarse, int check_orientation,
                                           int* matches12, int* n_matches);
+
+/* SearchForTriangulation with the per-candidate camera selection of keyframes that carry a second camera
+ * (ORBmatcher.cc:989-1006, :1099-1139).  Keypoint / descriptor arrays are combined (left first, right at n_left + i).
+ * n_left1 / n_left2 = KeyFrame::NLeft (-1: one camera; then cam[0], pose[0][0] and the epipole gate are used, and
+ * uright marks stereo keypoints).  pose[right1][right2] = {R12, t12} of the camera pair (Tll, Tlr, Trl, Trr),
+ * cam1[0/1] / cam2[0/1] = mpCamera / mpCamera2 of each keyframe.  The gate is pCamera1->epipolarConstrain(pCamera2, kp1,
+ * kp2, R12, t12, sigma1[kp1.octave], sigma2[kp2.octave]): Pinhole (Pinhole.cpp:118-141, with F12 = K1^-T [t12]x R12
+ * K2^-1) or KannalaBrandt8 (KannalaBrandt8.cpp:227-232, :323-397: unproject, parallax < 0.9998, triangulation,
+ * positive depths, reprojection errors <= 5.991 sigma).  If `gate` is set it replaces the built-in camera models:
+ * gate(gate_user, idx1, idx2) != 0 accepts -- an adapter passes the reference's own GeometricCamera objects through
+ * it, which keeps the decision bit-identical to the reference's whatever Eigen / libm it is built with. */
+enum { ORBX_CAMERA_PINHOLE = 0, ORBX_CAMERA_KANNALA_BRANDT8 = 1 };
+typedef struct orbx_camera_model {
+    int type;            /* ORBX_CAMERA_*                                              */
+    float params[8];     /* fx, fy, cx, cy (+ k0..k3 for KannalaBrandt8)               */
+} orbx_camera_model;
+typedef struct orbx_rel_pose { float R12[9]; float t12[3]; } orbx_rel_pose;   /* row-major rotation */
+typedef struct orbx_triangulation_geometry {
+    int n_left1, n_left2;
+    orbx_camera_model cam1[2], cam2[2];
+    orbx_rel_pose pose[2][2];
+    float epipole_x, epipole_y;        /* projection of camera centre 1 into image 2 (single-camera case) */
+    const float* scale_factors2;       /* mvScaleFactors of keyframe 2 */
+    const float* level_sigma2_1;       /* mvLevelSigma2 of keyframe 1 */
+    const float* level_sigma2_2;       /* mvLevelSigma2 of keyframe 2 */
+    int n_levels;
+    int (*gate)(void* user, int idx1, int idx2);
+    void* gate_user;
+} orbx_triangulation_geometry;
+orbx_status orbx_search_for_triangulation_cameras(const orbx_keypoint* kps1, const uint8_t* desc1, const uint8_t* free1,
+                                                  const float* uright1, int n1, const int* idx1, const int* off1,
+                                                  const orbx_keypoint* kps2, const uint8_t* desc2, const uint8_t* free2,
+                                                  const float* uright2, int n2, const int* idx2, const int* off2,
+                                                  int n_buckets, const orbx_triangulation_geometry* geom, int only_stereo,
+                                                  int coarse, int check_orientation, int* matches12, int* n_matches);
 
 /* ---- bag-of-words transform (the step between extraction and the BoW matchers) ----------
  * DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>::transform

@@ -106,6 +106,18 @@ def lib():
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_void_p]
         L.orc_bucket_best.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_search_by_projection_stereo.restype = C.c_int
+        L.orc_search_by_projection_stereo.argtypes = ([C.c_void_p] * 3 + [C.c_int]) * 2 + [C.c_void_p] * 9 + [C.c_int] + [C.c_void_p] * 4 + [C.c_float, C.c_void_p]
+        L.orc_search_window_best_stereo.restype = C.c_int
+        L.orc_search_window_best_stereo.argtypes = ([C.c_void_p] * 3 + [C.c_int]) * 2 + [C.c_void_p] * 11 + [C.c_int, C.c_float] + [C.c_void_p] * 3 + [C.c_float, C.c_void_p]
+        L.orc_search_for_triangulation_cameras.restype = C.c_int
+        L.orc_search_for_triangulation_cameras.argtypes = ([C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]) * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_float, C.c_float] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]
+        L.orc_kb8_triangulate_matches.restype = C.c_float
+        L.orc_kb8_triangulate_matches.argtypes = [C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+        L.orc_camera_project.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_camera_unproject.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_epipolar_constrain.restype = C.c_int
+        L.orc_epipolar_constrain.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_float, C.c_float]
         _lib = L
     return _lib
 
@@ -521,3 +533,90 @@ def distinctive_descriptors(desc, off):
     bm = np.zeros(n, np.int32)
     lib().orc_distinctive_descriptors(_p(desc), _p(off), n, _p(bi), _p(bm))
     return bi, bm
+
+
+# ---- second-camera (Nleft != -1) matcher paths ------------------------------------------------------------------
+
+def search_by_projection_stereo(gridL: Grid, descL, gridR, descR, left, right, qdesc, l2r, r2l, taken, marks, nnratio):
+    """SearchByProjection(Frame&, vector<MapPoint*>&, ...) with both camera passes.  left / right =
+    (x, y, radius, level) arrays (radius <= 0: not in that camera's view); gridR may be None (one camera).
+    Returns (kp_query over the combined index, taken_after, nmatches)."""
+    nL = len(gridL.kps)
+    nR = 0 if gridR is None else len(gridR.kps)
+    descL, qdesc = _u8(descL), _u8(qdesc)
+    descR = None if gridR is None else _u8(descR)
+    L = [_f32(left[0]), _f32(left[1]), _f32(left[2]), _i32(left[3])]
+    R = [_f32(right[0]), _f32(right[1]), _f32(right[2]), _i32(right[3])]
+    a = None if l2r is None else _i32(l2r)
+    b = None if r2l is None else _i32(r2l)
+    tk = _u8(taken).copy()
+    mk = _u8(marks)
+    out = np.zeros(nL + nR, np.int32)
+    n = lib().orc_search_by_projection_stereo(gridL.g, _p(gridL.kps), _p(descL), nL,
+                                              None if gridR is None else gridR.g, None if gridR is None else _p(gridR.kps),
+                                              _p(descR), nR, *[_p(x) for x in L], *[_p(x) for x in R], _p(qdesc), len(L[0]),
+                                              _p(a), _p(b), _p(tk), _p(mk), nnratio, _p(out))
+    return out, tk, n
+
+
+def search_window_best_stereo(gridL: Grid, descL, gridR, descR, left, right, qdesc, max_dist, taken, marks, qangle,
+                              factor=1.0 / 30):
+    """SearchByProjection(Frame& Cur, const Frame& Last, ...) with the right-image pass.  left / right =
+    (x, y, radius, min_level, max_level)."""
+    nL = len(gridL.kps)
+    nR = 0 if gridR is None else len(gridR.kps)
+    descL, qdesc = _u8(descL), _u8(qdesc)
+    descR = None if gridR is None else _u8(descR)
+    L = [_f32(left[0]), _f32(left[1]), _f32(left[2]), _i32(left[3]), _i32(left[4])]
+    R = [_f32(right[0]), _f32(right[1]), _f32(right[2]), _i32(right[3]), _i32(right[4])]
+    tk = _u8(taken).copy()
+    mk = _u8(marks)
+    qa = None if qangle is None else _f32(qangle)
+    out = np.zeros(nL + nR, np.int32)
+    n = lib().orc_search_window_best_stereo(gridL.g, _p(gridL.kps), _p(descL), nL,
+                                            None if gridR is None else gridR.g, None if gridR is None else _p(gridR.kps),
+                                            _p(descR), nR, *[_p(x) for x in L], *[_p(x) for x in R], _p(qdesc), len(L[0]),
+                                            max_dist, _p(tk), _p(mk), _p(qa), factor, _p(out))
+    return out, tk, n
+
+
+def search_for_triangulation_cameras(kps1, desc1, free1, ur1, n_left1, idx1, off1, kps2, desc2, free2, ur2, n_left2,
+                                     idx2, off2, cam_types, cam_params, poses, ep, scale_factors2, level_sigma2_1,
+                                     level_sigma2_2, only_stereo, coarse, check_ori):
+    """cam_types[4], cam_params[4][8] = {cam1 left, cam1 right, cam2 left, cam2 right}; poses[4][12] = ll, lr, rl, rr as
+    (R12 row-major, t12)."""
+    kps1, kps2 = np.ascontiguousarray(kps1), np.ascontiguousarray(kps2)
+    desc1, desc2 = _u8(desc1), _u8(desc2)
+    a = [_u8(free1), None if ur1 is None else _f32(ur1), _i32(idx1), _i32(off1)]
+    b = [_u8(free2), None if ur2 is None else _f32(ur2), _i32(idx2), _i32(off2)]
+    ct, cp, ps = _i32(cam_types), _f32(cam_params).reshape(32), _f32(poses).reshape(48)
+    sf, s1, s2 = _f32(scale_factors2), _f32(level_sigma2_1), _f32(level_sigma2_2)
+    out = np.zeros(len(kps1), np.int32)
+    n = lib().orc_search_for_triangulation_cameras(
+        _p(kps1), _p(desc1), _p(a[0]), _p(a[1]), len(kps1), n_left1, _p(a[2]), _p(a[3]),
+        _p(kps2), _p(desc2), _p(b[0]), _p(b[1]), len(kps2), n_left2, _p(b[2]), _p(b[3]), len(a[3]) - 1,
+        _p(ct), _p(cp), _p(ps), float(ep[0]), float(ep[1]), _p(sf), _p(s1), _p(s2),
+        int(only_stereo), int(coarse), int(check_ori), _p(out))
+    return out, n
+
+
+def camera_project(cam_type, params, xyz):
+    uv = np.zeros(2, np.float32)
+    lib().orc_camera_project(cam_type, _p(_f32(params)), _p(_f32(xyz)), _p(uv))
+    return uv
+
+
+def camera_unproject(cam_type, params, uv):
+    xyz = np.zeros(3, np.float32)
+    lib().orc_camera_unproject(cam_type, _p(_f32(params)), _p(_f32(uv)), _p(xyz))
+    return xyz
+
+
+def kb8_triangulate_matches(cam1, cam2, p1, p2, R12, t12, sigma1, sigma2):
+    return float(lib().orc_kb8_triangulate_matches(_p(_f32(cam1)), _p(_f32(cam2)), float(p1[0]), float(p1[1]), float(p2[0]),
+                                                   float(p2[1]), _p(_f32(R12).reshape(9)), _p(_f32(t12)), sigma1, sigma2))
+
+
+def epipolar_constrain(type1, cam1, type2, cam2, p1, p2, R12, t12, sigma1, sigma2):
+    return bool(lib().orc_epipolar_constrain(type1, _p(_f32(cam1)), type2, _p(_f32(cam2)), float(p1[0]), float(p1[1]),
+                                             float(p2[0]), float(p2[1]), _p(_f32(R12).reshape(9)), _p(_f32(t12)), sigma1, sigma2))

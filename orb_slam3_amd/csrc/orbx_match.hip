@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "orbx_common.h"
+#include "orbx_camera_gates.h"
 
 // --------------------------------------------------------------------------------------
 // small RAII helper for the synchronous host entry points
@@ -1721,6 +1722,144 @@ extern "C" orbx_status orbx_search_window_best(const orbx_keypoint* kps, const u
                                          rot_factor, match_out, kp_match, n_matches);
 }
 
+// ---- two-camera frames (Frame::Nleft != -1) -------------------------------------------------------------
+namespace {
+// Candidate lists copied out of the calling thread's arena (the next search on the thread reuses it).
+struct OwnedLists {
+    std::vector<int> off, idx, dist;
+    orbx_status fill(const orbx_frame* f, const orbx_query* queries, const uint8_t* query_desc, int n_query) {
+        if (!f || f->n == 0) { off.assign((size_t)n_query + 1, 0); idx.clear(); dist.clear(); return ORBX_OK; }
+        WindowLists L;
+        orbx_status s = frame_window_lists(*f, queries, query_desc, n_query, L);
+        if (s != ORBX_OK) return s;
+        off.assign(L.off, L.off + n_query + 1);
+        const int total = L.off[n_query];
+        idx.assign(L.idx, L.idx + total);
+        dist.assign(L.dist, L.dist + total);
+        return ORBX_OK;
+    }
+};
+}  // namespace
+
+extern "C" orbx_status orbx_frame_search_by_projection_stereo(const orbx_frame* left, const orbx_frame* right,
+                                                              const orbx_query* queries_left,
+                                                              const orbx_query* queries_right, const uint8_t* query_desc,
+                                                              int n_query, float nn_ratio, const int* left_to_right,
+                                                              const int* right_to_left, uint8_t* taken,
+                                                              const uint8_t* query_marks, int* kp_query, int* n_matches) {
+    ORBX_REQUIRE(left && n_matches && n_query >= 0, "null argument");
+    const int nL = left->n, nR = right ? right->n : 0;
+    ORBX_REQUIRE(nL + nR == 0 || (taken && kp_query), "null argument");
+    ORBX_REQUIRE(n_query == 0 || (queries_left && query_desc && (nR == 0 || queries_right)), "null argument");
+    OwnedLists LL, LR;
+    orbx_status s = LL.fill(left, queries_left, query_desc, n_query);
+    if (s == ORBX_OK && nR > 0) s = LR.fill(right, queries_right, query_desc, n_query);
+    if (s != ORBX_OK) return s;
+    const orbx_keypoint* kL = left->hostKps.data();
+    const orbx_keypoint* kR = nR ? right->hostKps.data() : nullptr;
+    for (int i = 0; i < nL + nR; ++i) kp_query[i] = -1;
+    int nm = 0;
+    for (int q = 0; q < n_query; ++q) {
+        const uint8_t mark = query_marks ? query_marks[q] : 1;
+        if (queries_left[q].radius > 0 && LL.off[q + 1] > LL.off[q]) {            // ORBmatcher.cc:60-144
+            int best = 256, bestLevel = -1, best2 = 256, bestLevel2 = -1, bestIdx = -1;
+            for (int c = LL.off[q]; c < LL.off[q + 1]; ++c) {
+                const int i = LL.idx[c];
+                if (taken[i]) continue;
+                const int d = LL.dist[c];
+                if (d < best) { best2 = best; best = d; bestLevel2 = bestLevel; bestLevel = kL[i].octave; bestIdx = i; }
+                else if (d < best2) { bestLevel2 = kL[i].octave; best2 = d; }
+            }
+            if (best <= 100 && !(bestLevel == bestLevel2 && best > nn_ratio * best2)) {
+                kp_query[bestIdx] = q; taken[bestIdx] = mark;
+                if (nR > 0 && left_to_right && left_to_right[bestIdx] != -1) {       // the stereo observation in the right camera
+                    const int r = left_to_right[bestIdx];
+                    ORBX_REQUIRE(r >= 0 && r < nR, "left_to_right[%d] out of range", bestIdx);
+                    kp_query[r + nL] = q; taken[r + nL] = mark;
+                    ++nm;
+                }
+                ++nm;
+            }
+        }
+        if (nR > 0 && queries_right[q].radius > 0 && LR.off[q + 1] > LR.off[q]) {  // :146-213
+            int best = 256, bestLevel = -1, best2 = 256, bestLevel2 = -1, bestIdx = -1;
+            for (int c = LR.off[q]; c < LR.off[q + 1]; ++c) {
+                const int i = LR.idx[c];
+                if (taken[i + nL]) continue;
+                const int d = LR.dist[c];
+                if (d < best) { best2 = best; best = d; bestLevel2 = bestLevel; bestLevel = kR[i].octave; bestIdx = i; }
+                else if (d < best2) { bestLevel2 = kR[i].octave; best2 = d; }
+            }
+            if (best <= 100 && !(bestLevel == bestLevel2 && best > nn_ratio * best2)) {
+                if (right_to_left && right_to_left[bestIdx] != -1) {
+                    const int l = right_to_left[bestIdx];
+                    ORBX_REQUIRE(l >= 0 && l < nL, "right_to_left[%d] out of range", bestIdx);
+                    kp_query[l] = q; taken[l] = mark;
+                    ++nm;
+                }
+                kp_query[bestIdx + nL] = q; taken[bestIdx + nL] = mark;
+                ++nm;
+            }
+        }
+    }
+    *n_matches = nm;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_frame_search_window_best_stereo(const orbx_frame* left, const orbx_frame* right,
+                                                            const orbx_query* queries_left, const orbx_query* queries_right,
+                                                            const uint8_t* query_desc, int n_query, float max_dist,
+                                                            uint8_t* taken, const uint8_t* query_marks,
+                                                            const float* query_angle, float rot_factor, int* kp_query,
+                                                            int* n_matches) {
+    ORBX_REQUIRE(left && n_matches && n_query >= 0, "null argument");
+    const int nL = left->n, nR = right ? right->n : 0;
+    ORBX_REQUIRE(nL + nR == 0 || (taken && kp_query), "null argument");
+    ORBX_REQUIRE(n_query == 0 || (queries_left && query_desc && (nR == 0 || queries_right)), "null argument");
+    OwnedLists LL, LR;
+    orbx_status s = LL.fill(left, queries_left, query_desc, n_query);
+    if (s == ORBX_OK && nR > 0) s = LR.fill(right, queries_right, query_desc, n_query);
+    if (s != ORBX_OK) return s;
+    const orbx_keypoint* kL = left->hostKps.data();
+    const orbx_keypoint* kR = nR ? right->hostKps.data() : nullptr;
+    for (int i = 0; i < nL + nR; ++i) kp_query[i] = -1;
+    RotHist hist(rot_factor);
+    int nm = 0;
+    for (int q = 0; q < n_query; ++q) {
+        if (!(queries_left[q].radius > 0)) continue;                 // not projected into the left image (:1795-1803)
+        if (LL.off[q + 1] == LL.off[q]) continue;                    // empty left window: no right pass either (:1820)
+        const uint8_t mark = query_marks ? query_marks[q] : 1;
+        int best = 256, bestIdx = -1;
+        for (int c = LL.off[q]; c < LL.off[q + 1]; ++c) {
+            const int i = LL.idx[c];
+            if (taken[i]) continue;
+            if (LL.dist[c] < best) { best = LL.dist[c]; bestIdx = i; }
+        }
+        if (bestIdx >= 0 && (float)best <= max_dist) {
+            kp_query[bestIdx] = q; taken[bestIdx] = mark;
+            ++nm;
+            if (query_angle) ORBX_REQUIRE(hist.add(query_angle[q], kL[bestIdx].angle, bestIdx), "rotation bin out of range (query %d)", q);
+        }
+        if (nR > 0) {                                                 // :1879-1944
+            best = 256; bestIdx = -1;
+            for (int c = LR.off[q]; c < LR.off[q + 1]; ++c) {
+                const int i = LR.idx[c];
+                if (taken[i + nL]) continue;
+                if (LR.dist[c] < best) { best = LR.dist[c]; bestIdx = i; }
+            }
+            if (bestIdx >= 0 && (float)best <= max_dist) {
+                kp_query[bestIdx + nL] = q; taken[bestIdx + nL] = mark;
+                ++nm;
+                if (query_angle)
+                    ORBX_REQUIRE(hist.add(query_angle[q], kR[bestIdx].angle, bestIdx + nL), "rotation bin out of range (query %d)", q);
+            }
+        }
+    }
+    if (query_angle) hist.for_each_rejected([&](int i) { kp_query[i] = -1; --nm; });
+    *n_matches = nm;
+    return ORBX_OK;
+}
+
 extern "C" orbx_status orbx_frame_fuse_search(const orbx_frame* f, const orbx_query* queries, const uint8_t* query_desc,
                                               int n_query, const float* inv_level_sigma2, int n_levels, int* match_out,
                                               int* n_matches) {
@@ -2099,6 +2238,89 @@ extern "C" orbx_status orbx_search_for_triangulation(const orbx_keypoint* kps1, 
                     if (den != 0) {
                         const float dsqr = num * num / den;
                         ok = dsqr < 3.84 * geom->level_sigma2_2[kp2.octave];
+                    }
+                }
+                if (ok) { bestIdx2 = i2; bestDist = d; }
+            }
+            if (bestIdx2 >= 0) {
+                matches12[i1] = bestIdx2;
+                ++nm;
+                if (check_orientation)
+                    ORBX_REQUIRE(hist.add(kp1.angle, kps2[bestIdx2].angle, i1), "rotation bin out of range");
+            }
+        }
+    }
+    if (check_orientation) hist.for_each_rejected([&](int i1) { matches12[i1] = -1; --nm; });
+    *n_matches = nm;
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_search_for_triangulation_cameras(const orbx_keypoint* kps1, const uint8_t* desc1,
+                                                             const uint8_t* free1, const float* uright1, int n1,
+                                                             const int* idx1, const int* off1,
+                                                             const orbx_keypoint* kps2, const uint8_t* desc2,
+                                                             const uint8_t* free2, const float* uright2, int n2,
+                                                             const int* idx2, const int* off2, int n_buckets,
+                                                             const orbx_triangulation_geometry* geom, int only_stereo,
+                                                             int coarse, int check_orientation, int* matches12,
+                                                             int* n_matches) {
+    ORBX_REQUIRE(n_matches && geom && (n1 == 0 || (kps1 && free1 && matches12)) && (n2 == 0 || (kps2 && free2)), "null argument");
+    ORBX_REQUIRE(geom->n_levels > 0 && geom->scale_factors2 && geom->level_sigma2_1 && geom->level_sigma2_2, "level tables missing");
+    for (int i = 0; i < n1; ++i)
+        ORBX_REQUIRE(kps1[i].octave >= 0 && kps1[i].octave < geom->n_levels, "keypoint %d of the first keyframe: octave out of range", i);
+    for (int i = 0; i < n2; ++i)
+        ORBX_REQUIRE(kps2[i].octave >= 0 && kps2[i].octave < geom->n_levels, "keypoint %d of the second keyframe: octave out of range", i);
+    const int nLeft1 = geom->n_left1, nLeft2 = geom->n_left2;
+    const bool twoCams = nLeft1 != -1 && nLeft2 != -1;
+    orbx_gates::Camera cams[4];
+    for (int c = 0; c < 4; ++c) {
+        const orbx_camera_model& m = c < 2 ? geom->cam1[c] : geom->cam2[c - 2];
+        ORBX_REQUIRE(m.type == ORBX_CAMERA_PINHOLE || m.type == ORBX_CAMERA_KANNALA_BRANDT8 || (!twoCams && (c & 1)),
+                     "unknown camera model type %d", m.type);
+        cams[c].type = m.type;
+        for (int k = 0; k < 8; ++k) cams[c].p[k] = m.params[k];
+    }
+    BucketPairs bp;
+    orbx_status s = bucket_allpairs_impl(desc1, n1, idx1, off1, desc2, n2, idx2, off2, n_buckets, bp);
+    if (s != ORBX_OK) return s;
+    for (int i = 0; i < n1; ++i) matches12[i] = -1;
+    RotHist hist(1.0f / kHistoLength);
+    int nm = 0;
+    for (int b = 0; b < n_buckets; ++b) {
+        const int jb = off2[b], je = off2[b + 1];
+        for (int e = off1[b]; e < off1[b + 1]; ++e) {
+            const int i1 = idx1[e];
+            if (!free1[i1]) continue;                                   // already has a map point (:1037)
+            const bool stereo1 = nLeft1 == -1 && uright1 && uright1[i1] >= 0;   // !mpCamera2 && mvuRight >= 0 (:1042)
+            if (only_stereo && !stereo1) continue;
+            const orbx_keypoint& kp1 = kps1[i1];
+            const bool right1 = !(nLeft1 == -1 || i1 < nLeft1);
+            const uint16_t* row = bp.dist.data() + bp.rowStart[e];
+            int bestDist = 50, bestIdx2 = -1;
+            for (int j = jb; j < je; ++j) {
+                const int i2 = idx2[j];
+                if (!free2[i2]) continue;
+                const bool stereo2 = nLeft2 == -1 && uright2 && uright2[i2] >= 0;
+                if (only_stereo && !stereo2) continue;
+                const int d = row[j - jb];
+                if (d > 50 || d > bestDist) continue;
+                const orbx_keypoint& kp2 = kps2[i2];
+                const bool right2 = !(nLeft2 == -1 || i2 < nLeft2);
+                if (!stereo1 && !stereo2 && nLeft1 == -1) {             // too close to the epipole (:1089-1097)
+                    const float distex = geom->epipole_x - kp2.x, distey = geom->epipole_y - kp2.y;
+                    if (distex * distex + distey * distey < 100 * geom->scale_factors2[kp2.octave]) continue;
+                }
+                bool ok = coarse != 0;
+                if (!ok) {
+                    if (geom->gate) {
+                        ok = geom->gate(geom->gate_user, i1, i2) != 0;
+                    } else {
+                        // camera pair and relative pose of this candidate (:1099-1137)
+                        const int sel = twoCams ? (right1 ? 2 : 0) + (right2 ? 1 : 0) : 0;
+                        const orbx_rel_pose& T = geom->pose[sel >> 1][sel & 1];
+                        ok = orbx_gates::epipolar_constrain(cams[twoCams && right1 ? 1 : 0], cams[2 + (twoCams && right2 ? 1 : 0)],
+                                                            kp1.x, kp1.y, kp2.x, kp2.y, T.R12, T.t12,
+                                                            geom->level_sigma2_1[kp1.octave], geom->level_sigma2_2[kp2.octave]);
                     }
                 }
                 if (ok) { bestIdx2 = i2; bestDist = d; }

@@ -335,6 +335,109 @@ class ORBmatcher:
         return out, nm.value
 
 
+    # ---- frames with a second camera (Frame::Nleft != -1) -----------------------------------
+    def SearchByProjectionStereoIn(self, left: FrameFeatures, right, queries_left, queries_right, query_desc, taken,
+                                   left_to_right=None, right_to_left=None, query_marks=None):
+        """SearchByProjection(Frame&, vector<MapPoint*>&, th, ...) with the left and the right camera pass
+        (ORBmatcher.cc:42-216).  right = FrameFeatures of the right camera or None; taken spans left + right
+        keypoints and is updated in place.  Returns (kp_query, n_matches)."""
+        ql, query_desc = self._queries(queries_left, query_desc)
+        qr = None if right is None else np.ascontiguousarray(queries_right, QUERY_DTYPE)
+        n = len(left) + (0 if right is None else len(right))
+        assert taken.dtype == np.uint8 and taken.flags.c_contiguous and len(taken) == n
+        l2r = None if left_to_right is None else np.ascontiguousarray(left_to_right, np.int32)
+        r2l = None if right_to_left is None else np.ascontiguousarray(right_to_left, np.int32)
+        marks = None if query_marks is None else np.ascontiguousarray(query_marks, np.uint8)
+        kpq = np.full(n, -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_frame_search_by_projection_stereo(left._h, None if right is None else right._h, ptr(ql), ptr(qr),
+                                                           ptr(query_desc), len(ql), float(self.mfNNratio), ptr(l2r),
+                                                           ptr(r2l), ptr(taken), ptr(marks), ptr(kpq), C.byref(nm)))
+        return kpq, nm.value
+
+    def SearchWindowBestStereoIn(self, left: FrameFeatures, right, queries_left, queries_right, query_desc, max_dist,
+                                 taken, query_marks=None, query_angle=None, rot_factor=1.0 / HISTO_LENGTH):
+        """SearchByProjection(Frame& Cur, const Frame& Last, th, bMono) with the right-image pass
+        (ORBmatcher.cc:1761-1972).  Returns (kp_query, n_matches)."""
+        ql, query_desc = self._queries(queries_left, query_desc)
+        qr = None if right is None else np.ascontiguousarray(queries_right, QUERY_DTYPE)
+        n = len(left) + (0 if right is None else len(right))
+        assert taken.dtype == np.uint8 and taken.flags.c_contiguous and len(taken) == n
+        marks = None if query_marks is None else np.ascontiguousarray(query_marks, np.uint8)
+        qa = None
+        if query_angle is not None and self.mbCheckOrientation:
+            qa = np.ascontiguousarray(query_angle, np.float32)
+        kpq = np.full(n, -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_frame_search_window_best_stereo(left._h, None if right is None else right._h, ptr(ql), ptr(qr),
+                                                         ptr(query_desc), len(ql), float(max_dist), ptr(taken), ptr(marks),
+                                                         ptr(qa), float(np.float32(rot_factor)), ptr(kpq), C.byref(nm)))
+        return kpq, nm.value
+
+    def SearchForTriangulationCameras(self, kps1, desc1, free1, uright1, n_left1, featvec1, kps2, desc2, free2, uright2,
+                                      n_left2, featvec2, cam_types, cam_params, poses, epipole, scale_factors2,
+                                      level_sigma2_1, level_sigma2_2, bOnlyStereo=False, bCoarse=False):
+        """SearchForTriangulation with the per-candidate camera pair (ORBmatcher.cc:968-1212 incl. :1099-1139).
+        cam_types[4] / cam_params[4][8] = {cam1 left, cam1 right, cam2 left, cam2 right};
+        poses[4][12] = (R12 row-major, t12) for ll, lr, rl, rr."""
+        kps1, desc1, ur1 = self._frame(kps1, desc1, uright1)
+        kps2, desc2, ur2 = self._frame(kps2, desc2, uright2)
+        a = [np.ascontiguousarray(free1, np.uint8), np.ascontiguousarray(featvec1[0], np.int32),
+             np.ascontiguousarray(featvec1[1], np.int32)]
+        b = [np.ascontiguousarray(free2, np.uint8), np.ascontiguousarray(featvec2[0], np.int32),
+             np.ascontiguousarray(featvec2[1], np.int32)]
+        sf = np.ascontiguousarray(scale_factors2, np.float32)
+        s1 = np.ascontiguousarray(level_sigma2_1, np.float32)
+        s2 = np.ascontiguousarray(level_sigma2_2, np.float32)
+        g = TriangulationGeometry()
+        g.n_left1, g.n_left2 = int(n_left1), int(n_left2)
+        cp = np.asarray(cam_params, np.float32).reshape(4, 8)
+        ps = np.asarray(poses, np.float32).reshape(4, 12)
+        for c in range(4):
+            m = g.cam1[c] if c < 2 else g.cam2[c - 2]
+            m.type = int(cam_types[c])
+            m.params[:] = [float(v) for v in cp[c]]
+            pose = g.pose[c >> 1][c & 1]
+            pose.R12[:] = [float(v) for v in ps[c, :9]]
+            pose.t12[:] = [float(v) for v in ps[c, 9:]]
+        g.epipole_x, g.epipole_y = float(epipole[0]), float(epipole[1])
+        g.scale_factors2 = sf.ctypes.data_as(C.POINTER(C.c_float))
+        g.level_sigma2_1 = s1.ctypes.data_as(C.POINTER(C.c_float))
+        g.level_sigma2_2 = s2.ctypes.data_as(C.POINTER(C.c_float))
+        g.n_levels = len(sf)
+        g.gate = None
+        g.gate_user = None
+        out = np.full(len(kps1), -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_search_for_triangulation_cameras(ptr(kps1), ptr(desc1), ptr(a[0]), ptr(ur1), len(kps1), ptr(a[1]),
+                                                          ptr(a[2]), ptr(kps2), ptr(desc2), ptr(b[0]), ptr(ur2), len(kps2),
+                                                          ptr(b[1]), ptr(b[2]), len(a[2]) - 1, C.byref(g), int(bOnlyStereo),
+                                                          int(bCoarse), int(self.mbCheckOrientation), ptr(out), C.byref(nm)))
+        return out, nm.value
+
+
+class CameraModel(C.Structure):
+    """orbx_camera_model (include/orbx.h)."""
+    _fields_ = [("type", C.c_int), ("params", C.c_float * 8)]
+
+
+class RelPose(C.Structure):
+    """orbx_rel_pose."""
+    _fields_ = [("R12", C.c_float * 9), ("t12", C.c_float * 3)]
+
+
+GATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
+
+
+class TriangulationGeometry(C.Structure):
+    """orbx_triangulation_geometry."""
+    _fields_ = [("n_left1", C.c_int), ("n_left2", C.c_int), ("cam1", CameraModel * 2), ("cam2", CameraModel * 2),
+                ("pose", (RelPose * 2) * 2), ("epipole_x", C.c_float), ("epipole_y", C.c_float),
+                ("scale_factors2", C.POINTER(C.c_float)), ("level_sigma2_1", C.POINTER(C.c_float)),
+                ("level_sigma2_2", C.POINTER(C.c_float)), ("n_levels", C.c_int), ("gate", C.c_void_p),
+                ("gate_user", C.c_void_p)]
+
+
 class Epipolar(C.Structure):
     """orbx_epipolar (include/orbx.h)."""
     _fields_ = [("F12", C.c_float * 9), ("epipole_x", C.c_float), ("epipole_y", C.c_float),
