@@ -585,6 +585,35 @@ orbx_status orbx_bow_vectors(orbx_vocabulary* voc, const uint8_t* desc, int n, i
 orbx_status orbx_distinctive_descriptors(const uint8_t* desc, const int* off, int n_points,
                                          int* best_idx, int* best_median);
 
+/* ---- saved-map records (the source of large map-descriptor sets) ------------------------------
+ * The reference writes keypoints and descriptors into its Atlas archives (System.cc:1568-1672, boost text or binary
+ * archive) through two templates: serializeMatrix (include/SerializationUtils.h:76-108: cols, rows, type,
+ * continuous, then the bytes) and serializeVectorKeyPoints (:125-169: NumEl, then per keypoint angle, response, size,
+ * pt.x, pt.y, class_id, octave); KeyFrame::serialize (include/KeyFrame.h:118-126) stores mvKeys, mvKeysUn and
+ * mDescriptors with them.  These functions read and write exactly those records inside an archive image held in
+ * memory (text != 0: boost text archive, every primitive a decimal token; else boost binary archive, native little
+ * endian).  Host memory, no device involved.  Parity unpinned: no saved map and no boost in the reference tree.
+ * read_*: the record starts at buf; *consumed = its length.  out may be NULL to query sizes.
+ * write_*: out may be NULL to query *written. */
+orbx_status orbx_archive_read_matrix(const uint8_t* buf, size_t len, int text, size_t* consumed, int* rows, int* cols,
+                                     int* cv_type, uint8_t* out, size_t capacity);
+orbx_status orbx_archive_write_matrix(const uint8_t* data, int rows, int cols, int cv_type, int text, uint8_t* out,
+                                      size_t capacity, size_t* written);
+orbx_status orbx_archive_read_keypoints(const uint8_t* buf, size_t len, int text, size_t* consumed, orbx_keypoint* out,
+                                        int capacity, int* n_out);
+orbx_status orbx_archive_write_keypoints(const orbx_keypoint* kps, int n, int text, uint8_t* out, size_t capacity,
+                                         size_t* written);
+/* Every descriptor matrix of an archive image, found by the header serializeMatrix gives it (32 columns, CV_8UC1,
+ * continuous, at least min_rows rows, payload inside the image) without interpreting the rest of the archive:
+ * KeyFrame::mDescriptors (rows = N) and, with min_rows = 1, MapPoint::mDescriptor.  payload_offset[i] / rows_out[i]
+ * (capacity entries, may be NULL to count) locate matrix i; *total_rows = descriptors in all of them.  In a binary
+ * archive the rows can be used in place (buf + payload_offset, rows x 32 bytes, e.g. uploaded shard by shard into
+ * orbx_hamming_knn2_device); orbx_archive_copy_descriptors decodes them for either format. */
+orbx_status orbx_archive_scan_descriptors(const uint8_t* buf, size_t len, int text, int min_rows, size_t* payload_offset,
+                                          int* rows_out, int capacity, int* n_found, long long* total_rows);
+orbx_status orbx_archive_copy_descriptors(const uint8_t* buf, size_t len, int text, size_t payload_offset, int rows,
+                                          uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,12 @@ PROTOTYPES = {
     "orbx_vocabulary_destroy": (None, [C.c_void_p]),
     "orbx_bow_transform": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orbx_bow_vectors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orbx_archive_read_matrix": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
+    "orbx_archive_write_matrix": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "orbx_archive_read_keypoints": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t), C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "orbx_archive_write_keypoints": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "orbx_archive_scan_descriptors": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    "orbx_archive_copy_descriptors": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_int, C.c_void_p]),
     "orbx_debug_wave_sort": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "orbx_debug_level_keypoints": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "orbx_descriptor_distance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -85,6 +85,33 @@ def test_knn2_sharded_merge_equals_single(oracle):
     assert np.array_equal(full.cpu().numpy(), oracle.knn2(q, t))
 
 
+@pytest.mark.parametrize("text", [False, True])
+def test_knn2_over_a_saved_map(oracle, tmp_path, text):
+    # descriptors streamed out of a saved-map image (serializeMatrix records, SerializationUtils.h:76-108) into the
+    # sharded search: contiguous shards of the file's descriptor rows, local top-2, merge = the search over all rows
+    A = _gpu()
+    import torch
+    from orb_slam3_amd import mapfile
+    q = synth.random_descriptors(300, 17)
+    t, _ = synth.planted_map(q, 6000, 18)
+    cuts = [0, 700, 701, 2600, 6000]                       # four keyframes' descriptor matrices
+    img = b"".join(b"\x05\0\0\0junk" * 3 + mapfile.write_matrix(t[a:b], text) for a, b in zip(cuts[:-1], cuts[1:]))
+    path = tmp_path / "map.osa"
+    path.write_bytes(img)
+    md = mapfile.MapDescriptors(str(path), text, min_rows=1)
+    assert len(md) == len(t)
+    dq = torch.from_numpy(q).cuda()
+    parts = []
+    for r in range(3):
+        base, rows = md.shard(r, 3)
+        p, _ = A.knn_match2_device(dq, torch.from_numpy(np.ascontiguousarray(rows)).cuda(), base_index=base)
+        parts.append(p)
+    merged = A.knn2_merge_device(torch.stack(parts))
+    torch.cuda.synchronize()
+    assert np.array_equal(merged.cpu().numpy(), oracle.knn2(q, t))
+    md.close()
+
+
 def test_knn2_full_size_properties():
     # the large-map search shape on one GPU shard of eight: 5000 queries against 1.25 M map descriptors
     # (one eighth of 10 M).  Too large for the oracle: checked through properties.
