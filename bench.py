@@ -14,9 +14,16 @@ descriptors against a 10 M descriptor map sharded in contiguous ranges over the 
 top-2 per rank, one RCCL all-gather of the 80 KB partial results, lexicographic merge.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (per-cell FAST): algorithmic bytes / hipEvent-timed duration
+  roofline      dominant kernel (per-cell FAST): algorithmic bytes / its launch duration, measured with hipEvents
+                on the launch stream in a pass of its own where nothing else runs beside it (so that the figure is
+                the kernel's duration, which rocprofv3 reports for the same launches); the duration it has in the
+                timed two-stream pass, where the other camera's kernels share the GPU, is given beside it
   path_roofline whole step: compulsory bytes per frame (input + pyramid + results) / step time
-  cpu_baseline  the CPU oracle (a plain port of the reference path) on a bounded sample
+  extract_1080p the 1920x1080 / 5000-feature batched extraction (distinct synthetic frames, 1024 frames per
+                measurement), with its per-kernel times and its fraction of the HBM roofline
+  host_path     the host entry points (pageable image in, keypoints / descriptors out: PCIe inclusive)
+  cpu_baseline  the CPU oracle (a plain port of the reference path) on a bounded sample: one thread, all cores,
+                and the matcher's distance loop with the reference's bit-hack popcount and with the hardware one
 """
 import argparse
 import json
@@ -32,7 +39,8 @@ sys.path.insert(0, ROOT)
 W, H, NFEAT, NLEVELS, SCALE, INI_TH, MIN_TH = 752, 480, 1000, 8, 1.2, 20, 7
 MBF, FX = 47.90639384423901, 435.2046959714599          # EuRoC-like baseline * fx and fx
 HBM_PEAK_GBS = 8000.0                                     # MI355X HBM3E spec
-VALU_U32_PEAK = 256 * 4 * 32 * 2.4e9                      # lane-ops/s (256 CU x 4 SIMD x 32 lanes x 2.4 GHz)
+VALU_U32_PEAK = 256 * 4 * 32 * 2.4e9                      # lane-ops/s (256 CU x 4 SIMD x 32 lanes x 2.4 GHz), nominal
+VALU_XOR_BCNT_MEASURED = 49.4e12                          # lane-ops/s of the search's own instruction pair, measured
 NQ_MAP, NT_MAP = 5000, 10_000_000
 
 
@@ -47,33 +55,56 @@ def level_pixels(ex):
 
 
 def cpu_baseline(n_pairs):
-    """The CPU oracle (single thread, a plain port of the reference path) on n_pairs stereo pairs."""
+    """The CPU oracle (a plain scalar port of the reference path) on a bounded sample: n_pairs stereo pairs on one
+    thread, then one pair per core on all cores of this job's CPU share, then the matcher's distance loop."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     from orb_slam3_amd import synth
     pairs = [synth.stereo_pair(W, H, 9000 + i) for i in range(n_pairs)]
-    eL = O.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
-    eR = O.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
-    t0 = time.perf_counter()
-    t_ext = 0.0
-    for L, R in pairs:
+
+    def one_pair(L, R):
+        eL = O.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
+        eR = O.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH)
         a = time.perf_counter()
         kL, dL, _ = eL(L, (0, 0))
         kR, dR, _ = eR(R, (0, 0))
-        t_ext += time.perf_counter() - a
+        t_ext = time.perf_counter() - a
         pl = [eL.pyramid_level(l) for l in range(NLEVELS)]
         pr = [eR.pyramid_level(l) for l in range(NLEVELS)]
         O.stereo_match(kL, dL, kR, dR, pl, pr, eL.scale_factors, eL.inv_scale_factors, MBF, MBF / FX)
+        return t_ext
+
+    t0 = time.perf_counter()
+    t_ext = sum(one_pair(L, R) for L, R in pairs)
     dt = time.perf_counter() - t0
-    # brute-force matcher sample (hardware popcount variant = the faster CPU form)
+    # all cores: the oracle is called through ctypes, which releases the interpreter lock, so threads run in parallel.
+    # OMP_NUM_THREADS carries this job's CPU share on the GPU box (os.cpu_count() reports the whole machine).
+    cores = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1), os.cpu_count() or 1))
+    work = [pairs[i % n_pairs] for i in range(2 * cores)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda p: one_pair(*p), work))
+    dt_all = time.perf_counter() - t0
+    # the matcher's inner loop (ORBmatcher::DescriptorDistance over a brute-force search): the reference's bit-hack
+    # popcount (ORBmatcher.cc:2141-2157) and __builtin_popcountll, one thread and all cores
     q = synth.random_descriptors(64, 5)
-    t = synth.random_descriptors(500_000, 6)
-    a = time.perf_counter()
-    O.knn2(q, t, True)
-    t_knn = time.perf_counter() - a
+    t = synth.random_descriptors(200_000, 6)
+    rates = {}
+    for name, fast in (("bit_hack", False), ("popcountll", True)):
+        a = time.perf_counter()
+        O.knn2(q, t, fast)
+        rates[name + "_1_core"] = 64 * 200_000 / (time.perf_counter() - a)
+        a = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            list(ex.map(lambda _: O.knn2(q, t, fast), range(cores)))
+        rates[name + "_all_cores"] = cores * 64 * 200_000 / (time.perf_counter() - a)
     return {"value": 2 * n_pairs / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"{n_pairs} synthetic 752x480 stereo pairs, CPU oracle: 2 extractions + stereo match per pair",
             "extract_ms_per_frame": 1e3 * t_ext / (2 * n_pairs),
-            "hamming_pairs_per_s": 64 * 500_000 / t_knn}
+            "all_cores": {"value": 2 * len(work) / dt_all, "unit": "frames/s", "cores": cores,
+                          "sample": f"{len(work)} pairs, one pair per thread at a time"},
+            "hamming_pairs_per_s": rates,
+            "hamming_sample": "64 queries x 200 000 map descriptors, brute force top-2"}
 
 
 def pick_concurrent_stream(torch, dev, first, candidates=6, cycles=200000):
@@ -110,6 +141,9 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="stereo pairs per step per GPU")
     ap.add_argument("--cpu-pairs", type=int, default=16, help="stereo pairs of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-hamming", action="store_true")
+    ap.add_argument("--no-1080p", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--batch-1080p", type=int, default=32, help="1920x1080 frames per launch per GPU")
     args = ap.parse_args()
 
     import torch
@@ -129,11 +163,11 @@ def main():
     from orb_slam3_amd import synth
 
     B = args.batch
-    # distinct frames per rank (seeded); a handful of distinct scenes tiled over the batch
-    n_unique = min(B, 8)
-    pairs = [synth.stereo_pair(W, H, 1000 * (rank + 1) + i) for i in range(n_unique)]
-    left = np.stack([pairs[i % n_unique][0] for i in range(B)])
-    right = np.stack([pairs[i % n_unique][1] for i in range(B)])
+    # B distinct stereo pairs per rank (seeded)
+    pairs = [synth.stereo_pair(W, H, 100000 * (rank + 1) + i) for i in range(B)]
+    left = np.stack([p[0] for p in pairs])
+    right = np.stack([p[1] for p in pairs])
+    del pairs
     dL = torch.from_numpy(left).to(dev)
     dR = torch.from_numpy(right).to(dev)
     exL = A.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local)
@@ -184,8 +218,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # The same K steps once more with a HIP event recorded on the launch stream between the
-    # kernels: per-kernel durations for the roofline.  (Each event costs a few microseconds of
-    # pipeline bubble, which is why `value` comes from the pass above.)
+    # kernels: per-kernel spans while the other camera's kernels share the GPU.  (Each event costs a few
+    # microseconds of pipeline bubble, which is why `value` comes from the pass above; under contention a span
+    # also holds the time a kernel waits for its turn, so it is an upper bound of the kernel's duration.)
     exL.set_timing(True); exR.set_timing(True)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -195,7 +230,19 @@ def main():
     dt_events = time.perf_counter() - t1
     tL, nL = exL.get_timing()
     tR, nR = exR.get_timing()
-    exL.set_timing(False); exR.set_timing(False)
+    exR.set_timing(False)
+    stage_ms_in_situ = {k: (tL[k] + tR[k]) / max(nL + nR, 1) for k in tL}       # per launch (B frames)
+    # Roofline pass: the left extractor alone on one stream, K launches, events between the kernels: with nothing
+    # beside it a span is the kernel's duration (what rocprofv3 reports for these launches).
+    exL.set_timing(True)
+    torch.cuda.synchronize()
+    for _ in range(args.steps):
+        with torch.cuda.stream(sL):
+            exL.extract_batch_device(dL, (0, 0), out=outL)
+    torch.cuda.synchronize()
+    tA, nA = exL.get_timing()
+    exL.set_timing(False)
+    stage_ms = {k: tA[k] / max(nA, 1) for k in tA}
     frames_per_step = 2 * B * world
     value = frames_per_step * args.steps / dt
     counts = outL[2].cpu().numpy()
@@ -204,21 +251,24 @@ def main():
 
     # --- roofline of the dominant kernel (FAST cells): pixels of every level read once + candidates written
     px = level_pixels(exL)
-    stage_ms = {k: (tL[k] + tR[k]) / max(nL + nR, 1) for k in tL}       # per launch (B frames)
     dominant = max(stage_ms, key=stage_ms.get)
     n_cand = 0
     for l in range(NLEVELS):
         n_cand += len(exL.debug_level_candidates(l, 0)[0])
     fast_bytes = B * (px + 16 * n_cand)
-    # HBM-side traffic of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same
-    # command, committed under profiles/ (FETCH_SIZE doubled: gfx950 tallies 128-byte reads as 64 bytes)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            t = json.load(f)
-        traffic = (t["fetch_correction"] * t["fetch_size_bytes_raw"] + t["write_size_bytes"]) * B / t["frames_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    # HBM-side traffic of that kernel is not measured by this run: it comes from separate rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE passes whose summary is committed under profiles/ (FETCH_SIZE doubled: gfx950 tallies 128-byte
+    # reads as 64 bytes); the JSON names that file as the source
+    traffic, traffic_src = None, None
+    for tag in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")) as f:
+                t = json.load(f)
+            traffic = (t["fetch_correction"] * t["fetch_size_bytes_raw"] + t["write_size_bytes"]) * B / t["frames_per_launch"]
+            traffic_src = f"committed profile profiles/{tag}_pmc_traffic.json (not measured by this run)"
+            break
+        except (OSError, KeyError, ValueError):
+            pass
     fast_s = stage_ms["fast"] * 1e-3
     achieved = fast_bytes / fast_s / 1e9 if fast_s > 0 else 0.0
     frame_bytes = W * H + px + 60 * n_kp                                   # input + pyramid + keypoints/descriptors
@@ -234,16 +284,100 @@ def main():
                    "pairs_per_step_per_gpu": B, "frames_per_step": frames_per_step,
                    "keypoints_per_frame": n_kp, "stereo_matches_frame0": n_match, "parallelism": f"frames sharded x{world}"},
         "roofline": {"bound": "hbm", "kernel": "k_fast", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": fast_bytes, "avg_launch_ms": stage_ms["fast"],
-                     "dominant_stage": dominant},
+                     "how": f"hipEvents around {nA} launches of {B} frames, the kernel alone on its stream "
+                            "(= the duration rocprofv3 reports for these launches)",
+                     "in_situ_span_ms": stage_ms_in_situ["fast"],
+                     "in_situ_note": "span between events in the timed two-stream pass: includes waiting behind the "
+                                     "other camera's kernels",
+                     "dominant_stage": dominant,
+                     "limit": "VALU issue, not HBM: see DESIGN.md section 7"},
         "path_roofline": {"bound": "hbm", "bytes_per_frame": frame_bytes, "achieved": path_achieved, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": path_achieved / HBM_PEAK_GBS},
         "stage_ms_per_launch": stage_ms,
-        "stage_timing": {"how": "second pass of the same K steps with hipEvents between the kernels",
+        "stage_ms_per_launch_in_situ": stage_ms_in_situ,
+        "stage_timing": {"how": "stage_ms_per_launch: the left extractor alone; ..._in_situ: second pass of the same K "
+                                "two-stream steps with hipEvents between the kernels",
                          "ms_per_step_with_events": 1e3 * dt_events / args.steps},
         "stream_overlap_ratio": overlap,
     }
+
+    # release the EuRoC buffers before the larger legs
+    del exL, exR, outL, outR, dL, dR, ur, depth
+    torch.cuda.empty_cache()
+
+    # --- 1920x1080 / 5000 features, batched extraction of distinct synthetic frames (1024 frames per measurement)
+    if not args.no_1080p:
+        HW, HH, HN, HB = 1920, 1080, 5000, args.batch_1080p
+        frames = np.stack([synth.scene(HW, HH, 500000 * (rank + 1) + i, n_prims=1500) for i in range(HB)])
+        dF = torch.from_numpy(frames).to(dev)
+        del frames
+        exH = A.ORBextractor(HN, SCALE, NLEVELS, INI_TH, MIN_TH, HW, HH, max_batch=HB, device=local)
+        capH = exH.max_keypoints
+        outH = (torch.empty((HB, capH, 28), dtype=torch.uint8, device=dev),
+                torch.empty((HB, capH, 32), dtype=torch.uint8, device=dev),
+                torch.empty((HB, 2), dtype=torch.int32, device=dev))
+        for _ in range(2):
+            exH.extract_batch_device(dF, (0, 0), out=outH)
+            torch.cuda.synchronize()
+            exH.status()
+        launches = max(1, 1024 // HB)
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(launches):
+            exH.extract_batch_device(dF, (0, 0), out=outH)
+        torch.cuda.synchronize(); barrier()
+        dth = time.perf_counter() - t0
+        exH.status()
+        if world > 1:
+            t = torch.tensor([dth], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dth = float(t.item())
+        exH.set_timing(True)
+        for _ in range(4):
+            exH.extract_batch_device(dF, (0, 0), out=outH)
+        torch.cuda.synchronize()
+        tH, nH = exH.get_timing()
+        exH.set_timing(False)
+        pxH = level_pixels(exH)
+        nkH = float(outH[2].cpu().numpy()[:, 0].mean())
+        bytesH = HW * HH + pxH + 60 * nkH
+        fpsH = launches * HB * world / dth
+        out["extract_1080p"] = {
+            "workload": f"synthetic 1920x1080, nFeatures=5000, 8 levels x1.2, FAST 20/7: {launches} launches of {HB} "
+                        f"distinct frames per GPU, one stream, inputs resident in HBM",
+            "frames_per_s": fpsH, "ms_per_frame": 1e3 * dth / (launches * HB), "keypoints_per_frame": nkH,
+            "bytes_per_frame": bytesH,
+            "path_roofline": {"bound": "hbm", "achieved": fpsH / world * bytesH / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": fpsH / world * bytesH / 1e9 / HBM_PEAK_GBS},
+            "stage_ms_per_launch": {k: tH[k] / max(nH, 1) for k in tH},
+            "scaling": "weak"}
+        del exH, outH, dF
+        torch.cuda.empty_cache()
+
+    # --- the host entry points: pageable image in, keypoints / descriptors in host memory out (PCIe inclusive)
+    if rank == 0 and not args.no_host_path:
+        imgs = [synth.scene(W, H, 40 + i) for i in range(8)]
+        ex1 = A.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, device=local)
+        for _ in range(3):
+            ex1(imgs[0], (0, 0))
+        t0 = time.perf_counter()
+        n1 = 100
+        for i in range(n1):
+            ex1(imgs[i % 8], (0, 0))
+        single = n1 / (time.perf_counter() - t0)
+        exb = A.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=64, device=local)
+        batch = [imgs[i % 8] for i in range(64)]
+        exb.extract_batch(batch, (0, 0))
+        t0 = time.perf_counter()
+        for _ in range(4):
+            exb.extract_batch(batch, (0, 0))
+        batched = 4 * 64 / (time.perf_counter() - t0)
+        out["host_path"] = {"what": "orbx_extract / orbx_extract_batch through the ctypes mirror: pageable 752x480 images in, "
+                                    "keypoints and descriptors in host memory out (H2D + kernels + D2H + synchronisation)",
+                            "orbx_extract_frames_per_s": single, "orbx_extract_batch64_frames_per_s": batched}
+        del ex1, exb
 
     # --- Hamming matches/s: 5000 queries vs 10 M map descriptors, sharded over the ranks
     if not args.no_hamming:
@@ -286,8 +420,13 @@ def main():
                           "matches_per_s": NQ_MAP / per, "pairs_per_s": pairs_s, "ms_per_search": 1e3 * per,
                           "scaling": "strong",
                           "roofline": {"bound": "valu-u32", "ops_per_pair": 16, "achieved": pairs_s * 16 / 1e12,
-                                       "peak": VALU_U32_PEAK * world / 1e12, "unit": "Tops/s",
-                                       "frac": pairs_s * 16 / (VALU_U32_PEAK * world)}}
+                                       "peak": VALU_XOR_BCNT_MEASURED * world / 1e12, "unit": "Tops/s",
+                                       "frac": pairs_s * 16 / (VALU_XOR_BCNT_MEASURED * world),
+                                       "peak_evidence": "profiles/r02_ubench_valu_issue.txt: the v_xor_b32 + "
+                                                        "v_bcnt_u32_b32 pair issues at 49.4 T lane-ops/s at 8 waves per "
+                                                        "SIMD (either instruction alone: 37.5 T; v_fma_f32: 56 T)",
+                                       "nominal_peak": VALU_U32_PEAK * world / 1e12,
+                                       "frac_of_nominal": pairs_s * 16 / (VALU_U32_PEAK * world)}}
 
     if rank == 0 and world == 1 and args.cpu_pairs > 0:
         out["cpu_baseline"] = cpu_baseline(args.cpu_pairs)

@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
 // Keypoints whose level-0 x lies inside [lap0, lap1] fill the arrays from the back,
 // the others from the front, both in (level, list) order.
 // ======================================================================================
-constexpr int kLayThreads = 1024;
+constexpr int kLayThreads = 256;     // small workgroups find room beside the other stream's kernels sooner
 
 __global__ __launch_bounds__(kLayThreads) void k_layout(const OrbxFrameGeo* __restrict__ geo,
                                                         OrbxLevelKp* __restrict__ levelKps,

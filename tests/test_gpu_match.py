@@ -95,7 +95,8 @@ def test_knn2_over_a_saved_map(oracle, tmp_path, text):
     q = synth.random_descriptors(300, 17)
     t, _ = synth.planted_map(q, 6000, 18)
     cuts = [0, 700, 701, 2600, 6000]                       # four keyframes' descriptor matrices
-    img = b"".join(b"\x05\0\0\0junk" * 3 + mapfile.write_matrix(t[a:b], text) for a, b in zip(cuts[:-1], cuts[1:]))
+    other = b" 5 0 other members" if text else b"\x05\0\0\0other members"      # what surrounds the records
+    img = b"".join(other * 3 + mapfile.write_matrix(t[a:b], text) for a, b in zip(cuts[:-1], cuts[1:]))
     path = tmp_path / "map.osa"
     path.write_bytes(img)
     md = mapfile.MapDescriptors(str(path), text, min_rows=1)
