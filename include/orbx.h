@@ -546,6 +546,25 @@ orbx_status orbx_search_for_triangulation_cameras(const orbx_keypoint* kps1, con
                                                   int n_buckets, const orbx_triangulation_geometry* geom, int only_stereo,
                                                   int coarse, int check_orientation, int* matches12, int* n_matches);
 
+/* The three bucketed searches on resident frames (orbx_frame holds mDescriptors on the device and the keypoints'
+ * angles, levels and mvuRight on the host): the same loops, results and order as the functions of the same name
+ * without "frame", minus the upload of both descriptor sets -- the FeatureVector CSR arrays go in and the distance
+ * rows come out through the calling thread's mapped pinned memory: one kernel launch and one synchronisation per
+ * call.  A two-camera Frame / KeyFrame is assigned with its combined arrays (left keypoints first; the grid of such a
+ * frame is not used by these searches).  orbx_frame_search_for_triangulation takes the geometry of
+ * orbx_search_for_triangulation_cameras (n_left = -1 and cam[0] / pose[0][0] for single-camera keyframes). */
+orbx_status orbx_frame_search_by_bow(const orbx_frame* kf, const uint8_t* valid_kf, const int* idx_kf, const int* off_kf,
+                                     const orbx_frame* f, int n_left_f, const int* idx_f, const int* off_f, int n_buckets,
+                                     float nn_ratio, int check_orientation, int* match_f, int* n_matches);
+orbx_status orbx_frame_search_by_bow_keyframes(const orbx_frame* kf1, const uint8_t* valid1, const int* idx1, const int* off1,
+                                               const orbx_frame* kf2, const uint8_t* valid2, const int* idx2, const int* off2,
+                                               int n_buckets, float nn_ratio, int check_orientation, int* matches12,
+                                               int* n_matches);
+orbx_status orbx_frame_search_for_triangulation(const orbx_frame* kf1, const uint8_t* free1, const int* idx1, const int* off1,
+                                                const orbx_frame* kf2, const uint8_t* free2, const int* idx2, const int* off2,
+                                                int n_buckets, const orbx_triangulation_geometry* geom, int only_stereo,
+                                                int coarse, int check_orientation, int* matches12, int* n_matches);
+
 /* ---- bag-of-words transform (the step between extraction and the BoW matchers) ----------
  * DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>::transform
  * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1112-1243; Frame::ComputeBoW, Frame.cc:872-879,

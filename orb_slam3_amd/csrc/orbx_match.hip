@@ -1183,6 +1183,7 @@ struct orbx_frame {
     float minX = 0, maxX = 0, minY = 0, maxY = 0, invW = 0, invH = 0;
     DevBuf kps, desc, uright, cellStart, cellIdx;
     std::vector<orbx_keypoint> hostKps;   // what the in-order loops read (level, angle, position)
+    std::vector<float> hostUright;        // mvuRight for the stereo flags of SearchForTriangulation
 };
 
 // cv::undistortPoints(src, dst, K, D, R = I, P = K) for one point, as Frame::UndistortKeyPoints and
@@ -1296,6 +1297,9 @@ orbx_status frame_assign(orbx_frame& F, const orbx_keypoint* kps, const uint8_t*
         ORBX_HIP_TRY(hipMemcpyAsync(F.kps.p, kps, (size_t)n * sizeof(orbx_keypoint), kind, st));
         ORBX_HIP_TRY(hipMemcpyAsync(F.desc.p, desc, (size_t)n * 32, kind, st));
         if (uright) ORBX_HIP_TRY(hipMemcpyAsync(F.uright.p, uright, (size_t)n * 4, kind, st));
+        F.hostUright.resize(uright ? (size_t)n : 0);
+        if (uright && fromDevice) ORBX_HIP_TRY(hipMemcpyAsync(F.hostUright.data(), uright, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        else if (uright) memcpy(F.hostUright.data(), uright, (size_t)n * 4);
         if (undistort) {
             // Frame::UndistortKeyPoints: the frame keeps mvKeysUn; the host mirror is read back
             hipLaunchKernelGGL(k_undistort, dim3((n + 255) / 256), dim3(256), 0, st, *undistort,
@@ -2025,15 +2029,19 @@ namespace {
 struct BucketPairs {
     std::vector<int> bucketOf;     // per idx1 entry
     std::vector<int> rowStart;     // per idx1 entry (+1)
-    std::vector<uint16_t> dist;    // rows of distances
+    const uint16_t* dist = nullptr;   // rows of distances, in the calling thread's pinned arena (valid until its next search)
+    size_t nPairs = 0;
 };
 }  // namespace
 
-static orbx_status bucket_allpairs_impl(const uint8_t* desc1, int n_desc1, const int* idx1, const int* off1,
-                                        const uint8_t* desc2, int n_desc2, const int* idx2, const int* off2, int n_buckets,
-                                        BucketPairs& bp) {
+// Distances of all bucket pairs with both descriptor sets already on the device: the five index arrays go in and the
+// distance rows come out through the calling thread's mapped pinned arena, so a search is one launch and one
+// synchronisation, without copy commands.
+static orbx_status bucket_pairs_dev(const uint32_t* dDesc1, int n_desc1, const int* idx1, const int* off1,
+                                    const uint32_t* dDesc2, int n_desc2, const int* idx2, const int* off2, int n_buckets,
+                                    BucketPairs& bp) {
     ORBX_REQUIRE(n_buckets >= 0 && n_desc1 >= 0 && n_desc2 >= 0, "negative size");
-    bp.bucketOf.clear(); bp.rowStart.assign(1, 0); bp.dist.clear();
+    bp.bucketOf.clear(); bp.rowStart.assign(1, 0); bp.dist = nullptr; bp.nPairs = 0;
     if (n_buckets == 0) return ORBX_OK;
     ORBX_REQUIRE(off1 && off2, "null argument");
     const int n1 = off1[n_buckets], n2 = off2[n_buckets];
@@ -2051,31 +2059,79 @@ static orbx_status bucket_allpairs_impl(const uint8_t* desc1, int n_desc1, const
         }
     }
     bp.rowStart[n1] = (int)total;
-    bp.dist.assign((size_t)total, 0);
+    bp.nPairs = (size_t)total;
     if (n1 == 0 || total == 0) return ORBX_OK;
-    ORBX_REQUIRE(desc1 && idx1 && desc2 && idx2, "null argument");
+    ORBX_REQUIRE(dDesc1 && idx1 && dDesc2 && idx2, "null argument");
     for (int i = 0; i < n1; ++i) ORBX_REQUIRE(idx1[i] >= 0 && idx1[i] < n_desc1, "idx1 out of range");
     for (int j = 0; j < n2; ++j) ORBX_REQUIRE(idx2[j] >= 0 && idx2[j] < n_desc2, "idx2 out of range");
     hipStream_t st;
     ORBX_HIP_TRY(thread_stream(&st));
-    DevBuf D1, D2, I1, I2, O2, BO, RS, OUT;
-    ORBX_HIP_TRY(D1.alloc((size_t)n_desc1 * 32)); ORBX_HIP_TRY(D2.alloc((size_t)n_desc2 * 32));
-    ORBX_HIP_TRY(I1.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(I2.alloc((size_t)n2 * 4));
-    ORBX_HIP_TRY(O2.alloc((size_t)(n_buckets + 1) * 4)); ORBX_HIP_TRY(BO.alloc((size_t)n1 * 4));
-    ORBX_HIP_TRY(RS.alloc((size_t)(n1 + 1) * 4)); ORBX_HIP_TRY(OUT.alloc((size_t)total * 2));
-    ORBX_HIP_TRY(copy_sync(D1.p, desc1, (size_t)n_desc1 * 32, hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(D2.p, desc2, (size_t)n_desc2 * 32, hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(I1.p, idx1, (size_t)n1 * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(I2.p, idx2, (size_t)n2 * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(O2.p, off2, (size_t)(n_buckets + 1) * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(BO.p, bp.bucketOf.data(), (size_t)n1 * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(RS.p, bp.rowStart.data(), (size_t)(n1 + 1) * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_bucket_allpairs, dim3((n1 + 3) / 4), dim3(256), 0, st, D1.as<uint32_t>(), I1.as<int>(),
-                       D2.as<uint32_t>(), I2.as<int>(), O2.as<int>(), BO.as<int>(), RS.as<int>(), n1, OUT.as<uint16_t>());
+    const size_t oI1 = 0, oI2 = align256(oI1 + (size_t)n1 * 4), oO2 = align256(oI2 + (size_t)n2 * 4);
+    const size_t oBO = align256(oO2 + (size_t)(n_buckets + 1) * 4), oRS = align256(oBO + (size_t)n1 * 4);
+    const size_t oOut = align256(oRS + (size_t)(n1 + 1) * 4);
+    ORBX_HIP_TRY(t_arena.ensure(oOut + (size_t)total * 2));
+    char* h = t_arena.host;
+    char* d = t_arena.dev;
+    memcpy(h + oI1, idx1, (size_t)n1 * 4);
+    memcpy(h + oI2, idx2, (size_t)n2 * 4);
+    memcpy(h + oO2, off2, (size_t)(n_buckets + 1) * 4);
+    memcpy(h + oBO, bp.bucketOf.data(), (size_t)n1 * 4);
+    memcpy(h + oRS, bp.rowStart.data(), (size_t)(n1 + 1) * 4);
+    hipLaunchKernelGGL(k_bucket_allpairs, dim3((n1 + 3) / 4), dim3(256), 0, st, dDesc1, reinterpret_cast<const int*>(d + oI1),
+                       dDesc2, reinterpret_cast<const int*>(d + oI2), reinterpret_cast<const int*>(d + oO2),
+                       reinterpret_cast<const int*>(d + oBO), reinterpret_cast<const int*>(d + oRS), n1,
+                       reinterpret_cast<uint16_t*>(d + oOut));
     ORBX_HIP_TRY(hipGetLastError());
-    ORBX_HIP_TRY(copy_sync(bp.dist.data(), OUT.p, (size_t)total * 2, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_TRY(hipStreamSynchronize(st));
+    bp.dist = reinterpret_cast<const uint16_t*>(h + oOut);
     return ORBX_OK;
 }
+
+// The same for descriptor sets in host memory: two uploads in front.
+static orbx_status bucket_allpairs_impl(const uint8_t* desc1, int n_desc1, const int* idx1, const int* off1,
+                                        const uint8_t* desc2, int n_desc2, const int* idx2, const int* off2, int n_buckets,
+                                        BucketPairs& bp) {
+    ORBX_REQUIRE(n_desc1 >= 0 && n_desc2 >= 0, "negative size");
+    ORBX_REQUIRE((n_desc1 == 0 || desc1) && (n_desc2 == 0 || desc2), "null argument");
+    hipStream_t st;
+    ORBX_HIP_TRY(thread_stream(&st));
+    DevBuf D1, D2;
+    ORBX_HIP_TRY(D1.alloc((size_t)std::max(n_desc1, 1) * 32)); ORBX_HIP_TRY(D2.alloc((size_t)std::max(n_desc2, 1) * 32));
+    if (n_desc1) ORBX_HIP_TRY(copy_sync(D1.p, desc1, (size_t)n_desc1 * 32, hipMemcpyHostToDevice, st));
+    if (n_desc2) ORBX_HIP_TRY(copy_sync(D2.p, desc2, (size_t)n_desc2 * 32, hipMemcpyHostToDevice, st));
+    return bucket_pairs_dev(D1.as<uint32_t>(), n_desc1, idx1, off1, D2.as<uint32_t>(), n_desc2, idx2, off2, n_buckets, bp);
+}
+
+// Two frames' descriptor sets as they lie on the device.
+static orbx_status bucket_pairs_frames(const orbx_frame* f1, const int* idx1, const int* off1, const orbx_frame* f2,
+                                       const int* idx2, const int* off2, int n_buckets, BucketPairs& bp) {
+    ORBX_REQUIRE(f1 && f2, "null frame");
+    ORBX_REQUIRE(f1->n == 0 || f2->n == 0 || f1->device == f2->device, "the two frames live on different devices");
+    int dev = 0;
+    ORBX_HIP_TRY(hipGetDevice(&dev));
+    const int want = f1->n ? f1->device : f2->device;
+    if (want >= 0 && dev != want) ORBX_HIP_TRY(hipSetDevice(want));
+    return bucket_pairs_dev(static_cast<const uint32_t*>(f1->desc.p), f1->n, idx1, off1,
+                            static_cast<const uint32_t*>(f2->desc.p), f2->n, idx2, off2, n_buckets, bp);
+}
+
+static orbx_status search_by_bow_replay(const BucketPairs& bp, const float* angle_kf, const uint8_t* valid_kf, const int* idx_kf,
+                                        const int* off_kf, const float* angle_f, int n_f, int n_left_f, const int* idx_f,
+                                        const int* off_f, int n_buckets, float nn_ratio, int check_orientation, int* match_f,
+                                        int* n_matches);
+static orbx_status search_by_bow_keyframes_replay(const BucketPairs& bp, const float* angle1, const uint8_t* valid1, int n1,
+                                                  const int* idx1, const int* off1, const float* angle2,
+                                                  const uint8_t* valid2, int n2, const int* idx2, const int* off2,
+                                                  int n_buckets, float nn_ratio, int check_orientation, int* matches12,
+                                                  int* n_matches);
+static orbx_status triangulation_check(const orbx_keypoint* kps1, int n1, const orbx_keypoint* kps2, int n2,
+                                       const orbx_triangulation_geometry* geom);
+static orbx_status triangulation_cameras_replay(const BucketPairs& bp, const orbx_keypoint* kps1, const uint8_t* free1,
+                                                const float* uright1, int n1, const int* idx1, const int* off1,
+                                                const orbx_keypoint* kps2, const uint8_t* free2, const float* uright2,
+                                                const int* idx2, const int* off2, int n_buckets,
+                                                const orbx_triangulation_geometry* geom, int only_stereo, int coarse,
+                                                int check_orientation, int* matches12, int* n_matches);
 
 extern "C" orbx_status orbx_bucket_allpairs(const uint8_t* desc1, int n_desc1, const int* idx1, const int* off1,
                                             const uint8_t* desc2, int n_desc2, const int* idx2, const int* off2,
@@ -2085,12 +2141,12 @@ extern "C" orbx_status orbx_bucket_allpairs(const uint8_t* desc1, int n_desc1, c
     BucketPairs bp;
     orbx_status s = bucket_allpairs_impl(desc1, n_desc1, idx1, off1, desc2, n_desc2, idx2, off2, n_buckets, bp);
     if (s != ORBX_OK) return s;
-    *n_pairs_out = bp.dist.size();
+    *n_pairs_out = bp.nPairs;
     if (n_buckets == 0) return ORBX_OK;
     ORBX_REQUIRE(row_start, "null argument");
     memcpy(row_start, bp.rowStart.data(), bp.rowStart.size() * sizeof(int));
-    if (bp.dist.size() > capacity) { orbx_set_error("%zu pairs, capacity %zu", bp.dist.size(), capacity); return ORBX_ERR_CAPACITY; }
-    if (!bp.dist.empty()) { ORBX_REQUIRE(dist, "null argument"); memcpy(dist, bp.dist.data(), bp.dist.size() * 2); }
+    if (bp.nPairs > capacity) { orbx_set_error("%zu pairs, capacity %zu", bp.nPairs, capacity); return ORBX_ERR_CAPACITY; }
+    if (bp.nPairs && bp.dist) { ORBX_REQUIRE(dist, "null argument"); memcpy(dist, bp.dist, bp.nPairs * 2); }
     return ORBX_OK;
 }
 
@@ -2104,6 +2160,15 @@ extern "C" orbx_status orbx_search_by_bow(const uint8_t* desc_kf, const float* a
     BucketPairs bp;
     orbx_status s = bucket_allpairs_impl(desc_kf, n_kf, idx_kf, off_kf, desc_f, n_f, idx_f, off_f, n_buckets, bp);
     if (s != ORBX_OK) return s;
+    return search_by_bow_replay(bp, angle_kf, valid_kf, idx_kf, off_kf, angle_f, n_f, n_left_f, idx_f, off_f, n_buckets,
+                                nn_ratio, check_orientation, match_f, n_matches);
+}
+
+// The loop of SearchByBoW(KeyFrame*, Frame&, ...) over the distance rows (ORBmatcher.cc:273-470).
+static orbx_status search_by_bow_replay(const BucketPairs& bp, const float* angle_kf, const uint8_t* valid_kf, const int* idx_kf,
+                                        const int* off_kf, const float* angle_f, int n_f, int n_left_f, const int* idx_f,
+                                        const int* off_f, int n_buckets, float nn_ratio, int check_orientation, int* match_f,
+                                        int* n_matches) {
     for (int i = 0; i < n_f; ++i) match_f[i] = -1;
     RotHist hist((float)kHistoLength / 360.0f);   // this fork's factor for this function (ORBmatcher.cc:255)
     int nm = 0;
@@ -2112,7 +2177,7 @@ extern "C" orbx_status orbx_search_by_bow(const uint8_t* desc_kf, const float* a
         for (int e = off_kf[b]; e < off_kf[b + 1]; ++e) {
             const int realIdxKF = idx_kf[e];
             if (!valid_kf[realIdxKF]) continue;
-            const uint16_t* row = bp.dist.data() + bp.rowStart[e];
+            const uint16_t* row = bp.dist + bp.rowStart[e];
             int best1 = 256, bestIdx = -1, best2 = 256, best1R = 256, bestIdxR = -1, best2R = 256;
             for (int j = jb; j < je; ++j) {
                 const int realIdxF = idx_f[j];
@@ -2157,6 +2222,16 @@ extern "C" orbx_status orbx_search_by_bow_keyframes(const uint8_t* desc1, const 
     BucketPairs bp;
     orbx_status s = bucket_allpairs_impl(desc1, n1, idx1, off1, desc2, n2, idx2, off2, n_buckets, bp);
     if (s != ORBX_OK) return s;
+    return search_by_bow_keyframes_replay(bp, angle1, valid1, n1, idx1, off1, angle2, valid2, n2, idx2, off2, n_buckets,
+                                          nn_ratio, check_orientation, matches12, n_matches);
+}
+
+// The loop of SearchByBoW(KeyFrame*, KeyFrame*, ...) over the distance rows (ORBmatcher.cc:856-964).
+static orbx_status search_by_bow_keyframes_replay(const BucketPairs& bp, const float* angle1, const uint8_t* valid1, int n1,
+                                                  const int* idx1, const int* off1, const float* angle2,
+                                                  const uint8_t* valid2, int n2, const int* idx2, const int* off2,
+                                                  int n_buckets, float nn_ratio, int check_orientation, int* matches12,
+                                                  int* n_matches) {
     for (int i = 0; i < n1; ++i) matches12[i] = -1;
     std::vector<uint8_t> matched2(n2, 0);
     RotHist hist(1.0f / kHistoLength);
@@ -2166,7 +2241,7 @@ extern "C" orbx_status orbx_search_by_bow_keyframes(const uint8_t* desc1, const 
         for (int e = off1[b]; e < off1[b + 1]; ++e) {
             const int i1 = idx1[e];
             if (!valid1[i1]) continue;
-            const uint16_t* row = bp.dist.data() + bp.rowStart[e];
+            const uint16_t* row = bp.dist + bp.rowStart[e];
             int best1 = 256, bestIdx2 = -1, best2 = 256;
             for (int j = jb; j < je; ++j) {
                 const int i2 = idx2[j];
@@ -2214,7 +2289,7 @@ extern "C" orbx_status orbx_search_for_triangulation(const orbx_keypoint* kps1, 
             const bool stereo1 = uright1 && uright1[i1] >= 0;
             if (only_stereo && !stereo1) continue;
             const orbx_keypoint& kp1 = kps1[i1];
-            const uint16_t* row = bp.dist.data() + bp.rowStart[e];
+            const uint16_t* row = bp.dist + bp.rowStart[e];
             int bestDist = 50, bestIdx2 = -1;
             for (int j = jb; j < je; ++j) {
                 const int i2 = idx2[j];
@@ -2265,11 +2340,32 @@ extern "C" orbx_status orbx_search_for_triangulation_cameras(const orbx_keypoint
                                                              int coarse, int check_orientation, int* matches12,
                                                              int* n_matches) {
     ORBX_REQUIRE(n_matches && geom && (n1 == 0 || (kps1 && free1 && matches12)) && (n2 == 0 || (kps2 && free2)), "null argument");
+    orbx_status chk = triangulation_check(kps1, n1, kps2, n2, geom);
+    if (chk != ORBX_OK) return chk;
+    BucketPairs bp;
+    orbx_status s = bucket_allpairs_impl(desc1, n1, idx1, off1, desc2, n2, idx2, off2, n_buckets, bp);
+    if (s != ORBX_OK) return s;
+    return triangulation_cameras_replay(bp, kps1, free1, uright1, n1, idx1, off1, kps2, free2, uright2, idx2, off2, n_buckets,
+                                        geom, only_stereo, coarse, check_orientation, matches12, n_matches);
+}
+
+static orbx_status triangulation_check(const orbx_keypoint* kps1, int n1, const orbx_keypoint* kps2, int n2,
+                                       const orbx_triangulation_geometry* geom) {
     ORBX_REQUIRE(geom->n_levels > 0 && geom->scale_factors2 && geom->level_sigma2_1 && geom->level_sigma2_2, "level tables missing");
     for (int i = 0; i < n1; ++i)
         ORBX_REQUIRE(kps1[i].octave >= 0 && kps1[i].octave < geom->n_levels, "keypoint %d of the first keyframe: octave out of range", i);
     for (int i = 0; i < n2; ++i)
         ORBX_REQUIRE(kps2[i].octave >= 0 && kps2[i].octave < geom->n_levels, "keypoint %d of the second keyframe: octave out of range", i);
+    return ORBX_OK;
+}
+
+// The loop of SearchForTriangulation over the distance rows (ORBmatcher.cc:1026-1199).
+static orbx_status triangulation_cameras_replay(const BucketPairs& bp, const orbx_keypoint* kps1, const uint8_t* free1,
+                                                const float* uright1, int n1, const int* idx1, const int* off1,
+                                                const orbx_keypoint* kps2, const uint8_t* free2, const float* uright2,
+                                                const int* idx2, const int* off2, int n_buckets,
+                                                const orbx_triangulation_geometry* geom, int only_stereo, int coarse,
+                                                int check_orientation, int* matches12, int* n_matches) {
     const int nLeft1 = geom->n_left1, nLeft2 = geom->n_left2;
     const bool twoCams = nLeft1 != -1 && nLeft2 != -1;
     orbx_gates::Camera cams[4];
@@ -2280,9 +2376,6 @@ extern "C" orbx_status orbx_search_for_triangulation_cameras(const orbx_keypoint
         cams[c].type = m.type;
         for (int k = 0; k < 8; ++k) cams[c].p[k] = m.params[k];
     }
-    BucketPairs bp;
-    orbx_status s = bucket_allpairs_impl(desc1, n1, idx1, off1, desc2, n2, idx2, off2, n_buckets, bp);
-    if (s != ORBX_OK) return s;
     for (int i = 0; i < n1; ++i) matches12[i] = -1;
     RotHist hist(1.0f / kHistoLength);
     int nm = 0;
@@ -2295,7 +2388,7 @@ extern "C" orbx_status orbx_search_for_triangulation_cameras(const orbx_keypoint
             if (only_stereo && !stereo1) continue;
             const orbx_keypoint& kp1 = kps1[i1];
             const bool right1 = !(nLeft1 == -1 || i1 < nLeft1);
-            const uint16_t* row = bp.dist.data() + bp.rowStart[e];
+            const uint16_t* row = bp.dist + bp.rowStart[e];
             int bestDist = 50, bestIdx2 = -1;
             for (int j = jb; j < je; ++j) {
                 const int i2 = idx2[j];
@@ -2336,6 +2429,60 @@ extern "C" orbx_status orbx_search_for_triangulation_cameras(const orbx_keypoint
     if (check_orientation) hist.for_each_rejected([&](int i1) { matches12[i1] = -1; --nm; });
     *n_matches = nm;
     return ORBX_OK;
+}
+
+// ---- the bucketed searches on resident frames: descriptors stay on the device, one launch + one synchronisation ----
+namespace {
+std::vector<float> frame_angles(const orbx_frame* f) {
+    std::vector<float> a((size_t)f->n);
+    for (int i = 0; i < f->n; ++i) a[i] = f->hostKps[i].angle;
+    return a;
+}
+}  // namespace
+
+extern "C" orbx_status orbx_frame_search_by_bow(const orbx_frame* kf, const uint8_t* valid_kf, const int* idx_kf,
+                                                const int* off_kf, const orbx_frame* f, int n_left_f, const int* idx_f,
+                                                const int* off_f, int n_buckets, float nn_ratio, int check_orientation,
+                                                int* match_f, int* n_matches) {
+    ORBX_REQUIRE(kf && f && n_matches && (f->n == 0 || match_f) && (kf->n == 0 || valid_kf), "null argument");
+    BucketPairs bp;
+    orbx_status s = bucket_pairs_frames(kf, idx_kf, off_kf, f, idx_f, off_f, n_buckets, bp);
+    if (s != ORBX_OK) return s;
+    const std::vector<float> aKF = frame_angles(kf), aF = frame_angles(f);
+    return search_by_bow_replay(bp, aKF.data(), valid_kf, idx_kf, off_kf, aF.data(), f->n, n_left_f, idx_f, off_f, n_buckets,
+                                nn_ratio, check_orientation, match_f, n_matches);
+}
+
+extern "C" orbx_status orbx_frame_search_by_bow_keyframes(const orbx_frame* kf1, const uint8_t* valid1, const int* idx1,
+                                                          const int* off1, const orbx_frame* kf2, const uint8_t* valid2,
+                                                          const int* idx2, const int* off2, int n_buckets, float nn_ratio,
+                                                          int check_orientation, int* matches12, int* n_matches) {
+    ORBX_REQUIRE(kf1 && kf2 && n_matches && (kf1->n == 0 || (matches12 && valid1)) && (kf2->n == 0 || valid2), "null argument");
+    BucketPairs bp;
+    orbx_status s = bucket_pairs_frames(kf1, idx1, off1, kf2, idx2, off2, n_buckets, bp);
+    if (s != ORBX_OK) return s;
+    const std::vector<float> a1 = frame_angles(kf1), a2 = frame_angles(kf2);
+    return search_by_bow_keyframes_replay(bp, a1.data(), valid1, kf1->n, idx1, off1, a2.data(), valid2, kf2->n, idx2, off2,
+                                          n_buckets, nn_ratio, check_orientation, matches12, n_matches);
+}
+
+extern "C" orbx_status orbx_frame_search_for_triangulation(const orbx_frame* kf1, const uint8_t* free1, const int* idx1,
+                                                           const int* off1, const orbx_frame* kf2, const uint8_t* free2,
+                                                           const int* idx2, const int* off2, int n_buckets,
+                                                           const orbx_triangulation_geometry* geom, int only_stereo,
+                                                           int coarse, int check_orientation, int* matches12,
+                                                           int* n_matches) {
+    ORBX_REQUIRE(kf1 && kf2 && n_matches && geom && (kf1->n == 0 || (free1 && matches12)) && (kf2->n == 0 || free2), "null argument");
+    const orbx_keypoint* kps1 = kf1->hostKps.data();
+    const orbx_keypoint* kps2 = kf2->hostKps.data();
+    orbx_status s = triangulation_check(kps1, kf1->n, kps2, kf2->n, geom);
+    if (s != ORBX_OK) return s;
+    BucketPairs bp;
+    s = bucket_pairs_frames(kf1, idx1, off1, kf2, idx2, off2, n_buckets, bp);
+    if (s != ORBX_OK) return s;
+    return triangulation_cameras_replay(bp, kps1, free1, kf1->hasUright ? kf1->hostUright.data() : nullptr, kf1->n, idx1, off1,
+                                        kps2, free2, kf2->hasUright ? kf2->hostUright.data() : nullptr, idx2, off2, n_buckets,
+                                        geom, only_stereo, coarse, check_orientation, matches12, n_matches);
 }
 
 // ======================================================================================

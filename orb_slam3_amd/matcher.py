@@ -386,27 +386,8 @@ class ORBmatcher:
              np.ascontiguousarray(featvec1[1], np.int32)]
         b = [np.ascontiguousarray(free2, np.uint8), np.ascontiguousarray(featvec2[0], np.int32),
              np.ascontiguousarray(featvec2[1], np.int32)]
-        sf = np.ascontiguousarray(scale_factors2, np.float32)
-        s1 = np.ascontiguousarray(level_sigma2_1, np.float32)
-        s2 = np.ascontiguousarray(level_sigma2_2, np.float32)
-        g = TriangulationGeometry()
-        g.n_left1, g.n_left2 = int(n_left1), int(n_left2)
-        cp = np.asarray(cam_params, np.float32).reshape(4, 8)
-        ps = np.asarray(poses, np.float32).reshape(4, 12)
-        for c in range(4):
-            m = g.cam1[c] if c < 2 else g.cam2[c - 2]
-            m.type = int(cam_types[c])
-            m.params[:] = [float(v) for v in cp[c]]
-            pose = g.pose[c >> 1][c & 1]
-            pose.R12[:] = [float(v) for v in ps[c, :9]]
-            pose.t12[:] = [float(v) for v in ps[c, 9:]]
-        g.epipole_x, g.epipole_y = float(epipole[0]), float(epipole[1])
-        g.scale_factors2 = sf.ctypes.data_as(C.POINTER(C.c_float))
-        g.level_sigma2_1 = s1.ctypes.data_as(C.POINTER(C.c_float))
-        g.level_sigma2_2 = s2.ctypes.data_as(C.POINTER(C.c_float))
-        g.n_levels = len(sf)
-        g.gate = None
-        g.gate_user = None
+        g, keep = triangulation_geometry(n_left1, n_left2, cam_types, cam_params, poses, epipole, scale_factors2,
+                                         level_sigma2_1, level_sigma2_2)
         out = np.full(len(kps1), -1, np.int32)
         nm = C.c_int()
         check(lib().orbx_search_for_triangulation_cameras(ptr(kps1), ptr(desc1), ptr(a[0]), ptr(ur1), len(kps1), ptr(a[1]),
@@ -414,6 +395,75 @@ class ORBmatcher:
                                                           ptr(b[1]), ptr(b[2]), len(a[2]) - 1, C.byref(g), int(bOnlyStereo),
                                                           int(bCoarse), int(self.mbCheckOrientation), ptr(out), C.byref(nm)))
         return out, nm.value
+
+
+    # ---- the bucketed searches on resident frames ---------------------------------------------
+    def SearchByBoWIn(self, kf: FrameFeatures, validKF, featvecKF, f: FrameFeatures, featvecF, n_left=-1):
+        """SearchByBoW(KeyFrame, Frame) with both descriptor sets resident on the device."""
+        a = [np.ascontiguousarray(validKF, np.uint8), np.ascontiguousarray(featvecKF[0], np.int32),
+             np.ascontiguousarray(featvecKF[1], np.int32)]
+        b = [np.ascontiguousarray(featvecF[0], np.int32), np.ascontiguousarray(featvecF[1], np.int32)]
+        out = np.full(len(f), -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_frame_search_by_bow(kf._h, ptr(a[0]), ptr(a[1]), ptr(a[2]), f._h, int(n_left), ptr(b[0]), ptr(b[1]),
+                                             len(a[2]) - 1, self.mfNNratio, int(self.mbCheckOrientation), ptr(out),
+                                             C.byref(nm)))
+        return out, nm.value
+
+    def SearchByBoWKeyFramesIn(self, kf1: FrameFeatures, valid1, featvec1, kf2: FrameFeatures, valid2, featvec2):
+        a = [np.ascontiguousarray(valid1, np.uint8), np.ascontiguousarray(featvec1[0], np.int32),
+             np.ascontiguousarray(featvec1[1], np.int32)]
+        b = [np.ascontiguousarray(valid2, np.uint8), np.ascontiguousarray(featvec2[0], np.int32),
+             np.ascontiguousarray(featvec2[1], np.int32)]
+        out = np.full(len(kf1), -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_frame_search_by_bow_keyframes(kf1._h, ptr(a[0]), ptr(a[1]), ptr(a[2]), kf2._h, ptr(b[0]), ptr(b[1]),
+                                                       ptr(b[2]), len(a[2]) - 1, self.mfNNratio,
+                                                       int(self.mbCheckOrientation), ptr(out), C.byref(nm)))
+        return out, nm.value
+
+    def SearchForTriangulationIn(self, kf1: FrameFeatures, free1, featvec1, kf2: FrameFeatures, free2, featvec2, geometry,
+                                 bOnlyStereo=False, bCoarse=False):
+        """geometry = triangulation_geometry(...)."""
+        g, keep = geometry
+        a = [np.ascontiguousarray(free1, np.uint8), np.ascontiguousarray(featvec1[0], np.int32),
+             np.ascontiguousarray(featvec1[1], np.int32)]
+        b = [np.ascontiguousarray(free2, np.uint8), np.ascontiguousarray(featvec2[0], np.int32),
+             np.ascontiguousarray(featvec2[1], np.int32)]
+        out = np.full(len(kf1), -1, np.int32)
+        nm = C.c_int()
+        check(lib().orbx_frame_search_for_triangulation(kf1._h, ptr(a[0]), ptr(a[1]), ptr(a[2]), kf2._h, ptr(b[0]), ptr(b[1]),
+                                                        ptr(b[2]), len(a[2]) - 1, C.byref(g), int(bOnlyStereo), int(bCoarse),
+                                                        int(self.mbCheckOrientation), ptr(out), C.byref(nm)))
+        return out, nm.value
+
+
+def triangulation_geometry(n_left1, n_left2, cam_types, cam_params, poses, epipole, scale_factors2, level_sigma2_1,
+                           level_sigma2_2):
+    """orbx_triangulation_geometry from flat arrays: cam_types[4] / cam_params[4][8] = {cam1 left, cam1 right, cam2 left,
+    cam2 right}; poses[4][12] = (R12 row-major, t12) for ll, lr, rl, rr.  Returns (struct, arrays it points into)."""
+    sf = np.ascontiguousarray(scale_factors2, np.float32)
+    s1 = np.ascontiguousarray(level_sigma2_1, np.float32)
+    s2 = np.ascontiguousarray(level_sigma2_2, np.float32)
+    g = TriangulationGeometry()
+    g.n_left1, g.n_left2 = int(n_left1), int(n_left2)
+    cp = np.asarray(cam_params, np.float32).reshape(4, 8)
+    ps = np.asarray(poses, np.float32).reshape(4, 12)
+    for c in range(4):
+        m = g.cam1[c] if c < 2 else g.cam2[c - 2]
+        m.type = int(cam_types[c])
+        m.params[:] = [float(v) for v in cp[c]]
+        pose = g.pose[c >> 1][c & 1]
+        pose.R12[:] = [float(v) for v in ps[c, :9]]
+        pose.t12[:] = [float(v) for v in ps[c, 9:]]
+    g.epipole_x, g.epipole_y = float(epipole[0]), float(epipole[1])
+    g.scale_factors2 = sf.ctypes.data_as(C.POINTER(C.c_float))
+    g.level_sigma2_1 = s1.ctypes.data_as(C.POINTER(C.c_float))
+    g.level_sigma2_2 = s2.ctypes.data_as(C.POINTER(C.c_float))
+    g.n_levels = len(sf)
+    g.gate = None
+    g.gate_user = None
+    return g, (sf, s1, s2)
 
 
 class CameraModel(C.Structure):

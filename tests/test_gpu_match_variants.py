@@ -166,6 +166,10 @@ def test_search_by_bow(oracle, n_left, check_ori):
     out, n = A.ORBmatcher(0.7, check_ori).SearchByBoW(descK, kpsK["angle"], validK, fvK, descF, kpsF["angle"], fvF, n_left)
     assert n == n_o and np.array_equal(out, out_o)
     assert (out >= 0).sum() > 10
+    # the same search on frames whose descriptors are resident on the device
+    fK, fF = A.FrameFeatures(kpsK, descK, None, BOUNDS), A.FrameFeatures(kpsF, descF, None, BOUNDS)
+    out2, n2 = A.ORBmatcher(0.7, check_ori).SearchByBoWIn(fK, validK, fvK, fF, fvF, n_left)
+    assert n2 == n_o and np.array_equal(out2, out_o)
 
 
 def test_search_by_bow_keyframes(oracle):
@@ -182,6 +186,9 @@ def test_search_by_bow_keyframes(oracle):
     out, n = A.ORBmatcher(0.9, True).SearchByBoWKeyFrames(desc1, kps1["angle"], v1, fv1, desc2, kps2["angle"], v2, fv2)
     assert n == n_o and np.array_equal(out, out_o)
     assert (out >= 0).sum() > 10
+    f1, f2 = A.FrameFeatures(kps1, desc1, None, BOUNDS), A.FrameFeatures(kps2, desc2, None, BOUNDS)
+    out2, n2 = A.ORBmatcher(0.9, True).SearchByBoWKeyFramesIn(f1, v1, fv1, f2, v2, fv2)
+    assert n2 == n_o and np.array_equal(out2, out_o)
 
 
 def _triangulation_case(rng, A):

@@ -263,6 +263,12 @@ def test_search_for_triangulation_camera_pairs(oracle, coarse, check_ori):
         k1, d1, f1, None, nl1, fv1, k2, d2, f2, None, nl2, fv2, cam_types, cam_params, poses, (0.0, 0.0), SF, sig2, sig2,
         False, coarse)
     assert n == n_o and np.array_equal(out, out_o)
+    # the same search on keyframes whose (combined) descriptor arrays are resident on the device
+    from orb_slam3_amd.matcher import triangulation_geometry
+    kf1, kf2 = A.FrameFeatures(k1, d1, None, BOUNDS), A.FrameFeatures(k2, d2, None, BOUNDS)
+    geom = triangulation_geometry(nl1, nl2, cam_types, cam_params, poses, (0.0, 0.0), SF, sig2, sig2)
+    out_f, n_f = A.ORBmatcher(0.6, check_ori).SearchForTriangulationIn(kf1, f1, fv1, kf2, f2, fv2, geom, False, coarse)
+    assert n_f == n_o and np.array_equal(out_f, out_o)
     m = np.nonzero(out >= 0)[0]
     assert len(m) > 60
     # all four camera pairs occur among the matches

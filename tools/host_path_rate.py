@@ -59,3 +59,37 @@ for name, fn in [("FrameFeatures.assign (upload + grid on the device)", lambda: 
         fn()
         ts.append(1e3 * (time.perf_counter() - t0))
     print(f"{name:55s} median {np.median(ts):7.3f} ms per call (min {min(ts):.3f}, max {max(ts):.3f})")
+
+# the bucketed searches (SearchByBoW between two keyframes of ~1000 keypoints over 300 shared vocabulary nodes): host
+# arrays in (both descriptor sets uploaded per call), resident frames, and the same loop with the distances computed
+# on one host core (numpy popcount table) for scale
+base = synth.random_descriptors(300, 80)
+k1, d1 = synth.matcher_frame(rng, 1000, base, 16)
+k2, d2 = synth.matcher_frame(rng, 1050, base, 16)
+v1 = np.ones(len(k1), np.uint8); v2 = np.ones(len(k2), np.uint8)
+fv1, fv2 = synth.feature_vector(rng, len(k1), 300), synth.feature_vector(rng, len(k2), 300)
+f1, f2 = A.FrameFeatures(k1, d1, None, bounds), A.FrameFeatures(k2, d2, None, bounds)
+mb = A.ORBmatcher(0.9, True)
+pop = np.array([bin(i).count("1") for i in range(256)], np.uint8)
+
+
+def host_pairs():
+    tot = 0
+    for b in range(300):
+        a = fv1[0][fv1[1][b]:fv1[1][b + 1]]; c = fv2[0][fv2[1][b]:fv2[1][b + 1]]
+        if len(a) and len(c):
+            tot += int(pop[d1[a][:, None, :] ^ d2[c][None, :, :]].sum(2).min())
+    return tot
+
+
+for name, fn in [("SearchByBoWKeyFrames (host arrays, 1000 x 1050 keypoints, 300 nodes)",
+                  lambda: mb.SearchByBoWKeyFrames(d1, k1["angle"], v1, fv1, d2, k2["angle"], v2, fv2)),
+                 ("SearchByBoWKeyFramesIn (resident frames)", lambda: mb.SearchByBoWKeyFramesIn(f1, v1, fv1, f2, v2, fv2)),
+                 ("the same pair distances on one host core (numpy)", host_pairs)]:
+    fn(); fn()
+    ts = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    print(f"{name:75s} median {np.median(ts):7.3f} ms per call (min {min(ts):.3f}, max {max(ts):.3f})")
