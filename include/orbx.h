@@ -207,9 +207,10 @@ orbx_status orbx_debug_wave_sort(const uint64_t* elems, const int* offsets, int 
 
 /* ---------------------------------------------------------------- matcher ---------- */
 
-/* The synchronous matcher entry points below keep their temporary device blocks in a per-thread
- * cache (at most 2 GiB) instead of freeing them; this returns the calling thread's cache to the
- * device.  No counterpart in the reference. */
+/* The synchronous matcher entry points below keep, per calling thread, their temporary device blocks
+ * (at most 2 GiB), a pinned staging arena, scratch frames and one stream per device instead of
+ * creating them per call; this gives all of them back for the calling thread.  The same happens by
+ * itself when a thread ends.  No counterpart in the reference. */
 void orbx_release_cached_memory(void);
 
 /* ORBmatcher::DescriptorDistance (ORBmatcher.cc:2141-2157) for n pairs: out[i] =

@@ -52,6 +52,7 @@ public:
         cellIdx.resize(n);
     }
     const orbx_frame* handle() const { return f_; }
+    orbx_frame* handle() { return f_; }
 
 private:
     orbx_frame* f_ = nullptr;

@@ -31,8 +31,18 @@ struct DevBlockCache {
     std::vector<Block> free;
     size_t cachedBytes = 0;
 };
+// Set once the calling thread's state below has been torn down (thread exit, or the main thread's part of process
+// exit); a trivially destructible flag, so it stays readable while static destructors run afterwards.
+thread_local bool t_threadStateGone = false;
 thread_local DevBlockCache t_cache;
 constexpr size_t kCacheLimit = (size_t)2 << 30;
+// Defined after t_cache, so constructed after it and destroyed before it: gives a thread's cached blocks, pinned
+// arena, scratch frames and streams back when the thread ends.
+struct ThreadCleanup {
+    ThreadCleanup() {}
+    ~ThreadCleanup();
+};
+thread_local ThreadCleanup t_cleanup;
 
 struct DevBuf {
     void* p = nullptr;
@@ -43,6 +53,12 @@ struct DevBuf {
         while (want < bytes) want <<= 1;
         hipError_t e = hipGetDevice(&device);
         if (e != hipSuccess) return e;
+        if (t_threadStateGone) {
+            e = hipMalloc(&p, want);
+            if (e == hipSuccess) cap = want; else p = nullptr;
+            return e;
+        }
+        (void)&t_cleanup;
         auto& f = t_cache.free;
         for (size_t i = 0; i < f.size(); ++i)
             if (f[i].cap == want && f[i].device == device) {
@@ -57,6 +73,12 @@ struct DevBuf {
     }
     void release() {
         if (!p) return;
+        if (t_threadStateGone) {
+            // a destructor running after this thread's state is gone (a static object at process exit): the runtime
+            // may be shutting down as well, so the block is left to the process teardown
+            p = nullptr; cap = 0;
+            return;
+        }
         if (t_cache.cachedBytes + cap <= kCacheLimit) {
             t_cache.free.push_back({p, cap, device});
             t_cache.cachedBytes += cap;
@@ -116,6 +138,7 @@ hipError_t thread_stream(hipStream_t* out) {
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= kMaxDevices) { *out = nullptr; return hipSuccess; }   // the default stream
+    (void)&t_cleanup;
     if (!t_streams[dev]) {
         e = hipStreamCreateWithFlags(&t_streams[dev], hipStreamNonBlocking);
         if (e != hipSuccess) return e;
@@ -138,11 +161,21 @@ hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kin
 static void release_thread_staging();   // the pinned arena and the scratch frames of the windowed searches
 
 extern "C" void orbx_release_cached_memory(void) {
+    if (t_threadStateGone) return;
     release_thread_staging();
     for (auto& b : t_cache.free) (void)hipFree(b.p);
     t_cache.free.clear();
     t_cache.cachedBytes = 0;
+    for (auto& st : t_streams)
+        if (st) { (void)hipStreamDestroy(st); st = nullptr; }
 }
+
+namespace {
+ThreadCleanup::~ThreadCleanup() {
+    orbx_release_cached_memory();
+    t_threadStateGone = true;
+}
+}  // namespace
 
 __device__ __forceinline__ int hamming256(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b) {
     int d = 0;

@@ -291,6 +291,37 @@ def test_window_candidates_match_get_features_in_area(oracle):
     assert off[-1] > 1000
 
 
+def test_short_lived_threads_and_explicit_release(oracle):
+    """The per-thread staging state (cached blocks, pinned arena, scratch frames, streams) is given back when a thread
+    ends and by orbx_release_cached_memory(); searches before and after either must agree."""
+    import threading
+    A = _gpu()
+    from orb_slam3_amd._lib import lib as load
+    e, k, d = _frame(oracle)
+    bounds = (0.0, 752.0, 0.0, 480.0)
+    rng = np.random.default_rng(3)
+    q = np.zeros(300, A.QUERY_DTYPE)
+    q["x"] = rng.uniform(0, 752, 300); q["y"] = rng.uniform(0, 480, 300)
+    q["radius"] = 25.0; q["min_level"] = -1; q["max_level"] = -1
+    qd = synth.random_descriptors(300, 5)
+    want = A.window_candidates(k, d, None, bounds, q, qd)
+    results = []
+
+    def work():
+        results.append(A.window_candidates(k, d, None, bounds, q, qd))
+        results.append(A.knn_match2(qd, d))
+    for _ in range(3):
+        t = threading.Thread(target=work)
+        t.start(); t.join()
+    load().orbx_release_cached_memory()
+    load().orbx_release_cached_memory()
+    again = A.window_candidates(k, d, None, bounds, q, qd)
+    for got in results[0::2] + [again]:
+        assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    for got in results[1::2]:
+        assert np.array_equal(got, A.knn_match2(qd, d))
+
+
 @pytest.mark.parametrize("stereo", [False, True])
 def test_search_by_projection_matches_oracle(oracle, stereo):
     A = _gpu()
