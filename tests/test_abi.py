@@ -98,3 +98,36 @@ def test_new_handles_validate_without_device(oracle):
     assert L.orbx_image_bounds(C.byref(cam), 752, 480, b.ctypes.data_as(C.c_void_p)) == _lib.ORBX_ERR_INVALID
     assert L.orbx_frame_assign(None, None, None, None, 0, 0.0, 1.0, 0.0, 1.0) == _lib.ORBX_ERR_INVALID
     assert L.orbx_frame_size(None) == 0
+
+
+def _declared_dist():
+    txt = open(os.path.join(ROOT, "include", "orbx_dist.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(orbx_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_dist_library_exports_and_validates_without_device():
+    """liborbx_dist.so (the multi-GPU entry points over RCCL) loads without a GPU, exports what include/orbx_dist.h
+    declares and rejects bad arguments before touching a device or a communicator."""
+    from orb_slam3_amd import _lib
+    _lib.lib()
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "liborbx_dist.so")
+    assert os.path.exists(path), "liborbx_dist.so not built (make -C orb_slam3_amd/csrc)"
+    D = C.CDLL(path)
+    names = _declared_dist()
+    assert len(names) == 9
+    for name in names:
+        assert hasattr(D, name), f"missing export {name}"
+    D.orbx_knn2_sharded_workspace_bytes.restype = C.c_size_t
+    D.orbx_knn2_sharded_workspace_bytes.argtypes = [C.c_int, C.c_int64, C.c_int]
+    L = _lib.lib()
+    one = D.orbx_knn2_sharded_workspace_bytes(5000, 1_250_000, 1)
+    eight = D.orbx_knn2_sharded_workspace_bytes(5000, 1_250_000, 8)
+    assert eight - one == 7 * 80128 and one > L.orbx_knn2_workspace_bytes(5000, 1_250_000)
+    assert D.orbx_knn2_sharded_workspace_bytes(-1, 10, 1) == 0 and D.orbx_knn2_sharded_workspace_bytes(10, 10, 0) == 0
+    D.orbx_hamming_knn2_sharded_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    assert D.orbx_hamming_knn2_sharded_device(None, 10, None, 10, 0, None, None, None, 0, None) == _lib.ORBX_ERR_INVALID
+    assert b"communicator" in L.orbx_last_error()
+    assert D.orbx_extract_pool_devices(None) == 0
+    assert D.orbx_rccl_unique_id(None) == _lib.ORBX_ERR_INVALID

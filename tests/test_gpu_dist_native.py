@@ -1,0 +1,25 @@
+"""The multi-GPU C ABI (include/orbx_dist.h, liborbx_dist.so) exercised by a native program on the GPUs the box
+shows: the sharded k = 2 search over a real RCCL communicator (world size 1 here; more ranks are not run on this
+pool) and the extractor pool, each compared with the single-GPU entry point in the same program."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "orb_slam3_amd", "lib", "dist_demo")
+
+
+def test_sharded_search_and_extractor_pool():
+    assert os.path.exists(DEMO), "dist_demo not built (make -C orb_slam3_amd/csrc)"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([DEMO], capture_output=True, text=True, timeout=170, env=env)
+    assert run.returncode == 0, run.stdout + run.stderr
+    out = run.stdout
+    for line in ("sharded_world1=OK", "sharded_base_index=OK", "sharded_empty=OK", "sharded_short_workspace=refused",
+                 "pool_frames=OK", "pool_bad_device=refused"):
+        assert line in out, out
+    n = int(out.split("keypoints=")[1].split()[0])
+    assert n > 2000
