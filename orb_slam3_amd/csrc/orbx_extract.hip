@@ -195,12 +195,16 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__
 }
 
 // Copies n_frames images (row_stride / frame_stride) into level 0 of each pyramid slab,
-// 16 bytes per lane when the source is 16-byte aligned, bytes otherwise.
+// 16 bytes per lane when the source is 16-byte aligned, bytes otherwise.  The first workgroup of every frame also
+// clears the frame's FAST candidate counters (the only per-batch state that must start at zero), which saves a
+// separate memset on the stream.
 __global__ __launch_bounds__(256) void k_copy_level0(const OrbxFrameGeo* __restrict__ geo,
                                                      const uint8_t* __restrict__ images, long long rowStride,
                                                      long long imgStride, uint8_t* __restrict__ pyr,
-                                                     long long frameStride, int aligned16, int chunksPerRow) {
+                                                     long long frameStride, int aligned16, int chunksPerRow,
+                                                     int* __restrict__ candCount) {
     const OrbxLevelGeo& D = geo->lv[0];
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)geo->nlevels) candCount[blockIdx.y * geo->nlevels + threadIdx.x] = 0;
     // the 16-byte chunks of a frame as one sequence: full workgroups whatever the image width
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = i / chunksPerRow;
@@ -302,7 +306,7 @@ constexpr int kFastThreads = 128;
 // cycles it spent between the phase boundaries of k_fast to a device array; the product library contains none of it.
 #ifdef ORBX_FAST_STAMPS
 constexpr int kStampWgs = 1 << 18;
-__device__ unsigned int g_fastStamps[kStampWgs][6];     // per workgroup: 5 phase durations + a "ran" mark
+__device__ unsigned int g_fastStamps[kStampWgs][8];     // per workgroup: 5 phase durations, a "ran" mark, survivors of the quick reject, corners of wave 0
 #define ORBX_STAMP(slot)                                                                   \
     do {                                                                                   \
         const unsigned long long now__ = __builtin_amdgcn_s_memtime();                     \
@@ -315,12 +319,14 @@ __device__ unsigned int g_fastStamps[kStampWgs][6];     // per workgroup: 5 phas
     unsigned long long stampPrev = __builtin_amdgcn_s_memtime()
 // Sums over the workgroups that ran since the last reset: out8[0..4] = cycles per phase, out8[7] = workgroups.
 extern "C" int orbx_debug_fast_stamps(unsigned long long* out8, int reset) {
-    std::vector<unsigned int> h((size_t)kStampWgs * 6);
+    std::vector<unsigned int> h((size_t)kStampWgs * 8);
     if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_fastStamps), h.size() * 4) != hipSuccess) return -1;
     for (int k = 0; k < 8; ++k) out8[k] = 0;
     for (int w = 0; w < kStampWgs; ++w) {
-        if (!h[(size_t)w * 6 + 5]) continue;
-        for (int k = 0; k < 5; ++k) out8[k] += h[(size_t)w * 6 + k];
+        if (!h[(size_t)w * 8 + 5]) continue;
+        for (int k = 0; k < 5; ++k) out8[k] += h[(size_t)w * 8 + k];
+        out8[5] += h[(size_t)w * 8 + 6];
+        out8[6] += h[(size_t)w * 8 + 7];
         ++out8[7];
     }
     if (reset) {
@@ -361,6 +367,18 @@ extern "C" int orbx_debug_desc_stamps(unsigned long long* out8, int reset) {
 #define ORBX_STAMP_BEGIN() do {} while (0)
 #define ORBX_DSTAMP(slot) do {} while (0)
 #define ORBX_DSTAMP_BEGIN() do {} while (0)
+#endif
+// Diagnostic builds only (-DORBX_FAST_STOP=n / -DORBX_DESC_STOP=n): the kernel ends after its n-th phase, so that the
+// instruction counters of successive builds differ by exactly one phase.  Results are meaningless in such a build.
+#ifdef ORBX_FAST_STOP
+#define ORBX_FAST_PHASE_END(n) do { if (ORBX_FAST_STOP == (n)) return; } while (0)
+#else
+#define ORBX_FAST_PHASE_END(n) do {} while (0)
+#endif
+#ifdef ORBX_DESC_STOP
+#define ORBX_DESC_PHASE_END(n) do { if (ORBX_DESC_STOP == (n)) return; } while (0)
+#else
+#define ORBX_DESC_PHASE_END(n) do {} while (0)
 #endif
 
 // kP = LDS tile pitch known at compile time (row steps and the 3-row look-ahead become
@@ -447,6 +465,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     }
     __syncthreads();
     ORBX_STAMP(0);   // tile load
+    ORBX_FAST_PHASE_END(1);
 
     const int iw = tw - 6, ih = th - 6;   // pixels FAST can test
     const int lowTh = min(iniTh, minTh);
@@ -454,15 +473,17 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     uint8_t* S = strength + ox;
     if (iw > 0 && ih > 0) {
         // (A) quick reject.  An arc of 9 contiguous circle pixels contains one pixel of every
-        // antipodal pair, so a corner needs, on one side of the (lower) threshold, a member of
-        // {0,8} (the pixels 3 rows below / above) AND a member of {4,12} (3 columns right / left).
+        // antipodal pair, so a corner needs, on one side of the (lower) threshold, a member of each of
+        // {0,8} (3 rows below / above), {4,12} (3 columns right / left) and the diagonal pairs {2,10}, {6,14}.
+        // (Two pairs let about a quarter of a textured image through, four pairs about a third of that, and
+        // every survivor costs a full arc evaluation in (B).)
         // Four pixels (one tile dword) per lane and step, compared byte-wise with v_lerp_u8:
         //   lerp(a, ~b, c) = (a - b + 255 + c) >> 1 per byte, so with c chosen to make t + 256 + c even
         //   "a - b > t"  <=>  lerp(a, ~b, c) >= K := (t + 256 + c) / 2  <=>  bit 7 of lerp(lerp(a, ~b, c), ~K, 1).
         // Three lerps per neighbour: the half-difference, its test against K (brighter) and against Z (darker).
         // The testable pixels are cut into horizontal bands; a lane walks down one dword column of one
-        // band with that column's 7 rows (y-3 .. y+3) in registers, so each further 4 pixels cost three
-        // LDS dword reads.  One wave does the whole cell (fewer instructions than two waves with
+        // band with the 7 rows (y-3 .. y+3) of that column and of its two neighbours in registers, so each
+        // further 4 pixels cost three LDS dword reads.  One wave does the whole cell (fewer instructions than two waves with
         // shorter bands); survivors are collected in a per-lane nibble mask and queued at the end.
         if (tid < 64) {
             const int t1 = lowTh + 1;                                  // a - b >= t1
@@ -496,37 +517,55 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
                 const int rows = min(8, bandRows - chunk);             // uniform
                 const uint32_t* c = reinterpret_cast<const uint32_t*>(tile + (laneOn ? yc : 3) * P) + (laneOn ? d : 1);
                 const int PD = P >> 2;                                 // row pitch in dwords
-                uint32_t w0 = c[-3 * PD], w1 = c[-2 * PD], w2 = c[-PD], w3 = c[0], w4 = c[PD], w5 = c[2 * PD], w6 = c[3 * PD];
+                // the dword columns left and right of the lane's own (clamped to the row: a clamped column is only
+                // ever the source of bytes that no testable pixel of this lane uses)
+                const int dl = (laneOn && d > 0) ? -1 : 0, dr = (laneOn && d + 1 < PD) ? 1 : 0;
+                // rows y-3 .. y+3 of the three columns, rotated through registers
+                uint32_t C0 = c[-3 * PD], C1 = c[-2 * PD], C2 = c[-PD], C3 = c[0], C4 = c[PD], C5 = c[2 * PD], C6 = c[3 * PD];
+                uint32_t L0 = c[-3 * PD + dl], L1 = c[-2 * PD + dl], L2 = c[-PD + dl], L3 = c[dl], L4 = c[PD + dl],
+                         L5 = c[2 * PD + dl], L6 = c[3 * PD + dl];
+                uint32_t R0 = c[-3 * PD + dr], R1 = c[-2 * PD + dr], R2 = c[-PD + dr], R3 = c[dr], R4 = c[PD + dr],
+                         R5 = c[2 * PD + dr], R6 = c[3 * PD + dr];
                 uint32_t mask = 0;   // row yc + i of the chunk ends up in nibble rows - 1 - i
-#define ORBX_FAST_ROW4(a0, a1, a2, a3, a4, a5, a6, r)                                                       \
+                // circle pixels used: 0 / 8 (0, +-3), 4 / 12 (+-3, 0), 2 / 10 (+2, +2) / (-2, -2), 6 / 14 (+2, -2) / (-2, +2)
+#define ORBX_H(px) __builtin_amdgcn_lerp(px, nC, cRound)
+#define ORBX_B(h) __builtin_amdgcn_lerp(h, nK, 0x01010101u)
+#define ORBX_E(h) __builtin_amdgcn_lerp(h, nZ, 0x01010101u)
+#define ORBX_FAST_ROW4(i0, i1, i2, i3, i4, i5, i6, r)                                                       \
                 if ((r) < rows) {                                                                           \
-                    const uint32_t C = a3, nC = ~C;                                                         \
-                    const uint32_t Lw = __builtin_amdgcn_alignbyte(C, c[-1], 1);   /* pixels x - 3 */       \
-                    const uint32_t Rw = __builtin_amdgcn_alignbyte(c[1], C, 3);    /* pixels x + 3 */       \
+                    const uint32_t nC = ~C##i3;                                                             \
                     /* per byte (neighbour - centre + 255 + c) >> 1: one value serves both polarities */    \
-                    const uint32_t hU = __builtin_amdgcn_lerp(a0, nC, cRound), hD = __builtin_amdgcn_lerp(a6, nC, cRound); \
-                    const uint32_t hL = __builtin_amdgcn_lerp(Lw, nC, cRound), hR = __builtin_amdgcn_lerp(Rw, nC, cRound); \
-                    /* bit 7: neighbour brighter than the centre by more than the threshold */              \
-                    const uint32_t bU = __builtin_amdgcn_lerp(hU, nK, 0x01010101u), bD = __builtin_amdgcn_lerp(hD, nK, 0x01010101u); \
-                    const uint32_t bL = __builtin_amdgcn_lerp(hL, nK, 0x01010101u), bR = __builtin_amdgcn_lerp(hR, nK, 0x01010101u); \
+                    const uint32_t hU = ORBX_H(C##i0), hD = ORBX_H(C##i6);                                  \
+                    const uint32_t hL = ORBX_H(__builtin_amdgcn_alignbyte(C##i3, L##i3, 1));   /* x - 3 */  \
+                    const uint32_t hR = ORBX_H(__builtin_amdgcn_alignbyte(R##i3, C##i3, 3));   /* x + 3 */  \
+                    const uint32_t hA = ORBX_H(__builtin_amdgcn_alignbyte(R##i5, C##i5, 2));   /* (+2, +2) */ \
+                    const uint32_t hB = ORBX_H(__builtin_amdgcn_alignbyte(C##i1, L##i1, 2));   /* (-2, -2) */ \
+                    const uint32_t hP = ORBX_H(__builtin_amdgcn_alignbyte(R##i1, C##i1, 2));   /* (+2, -2) */ \
+                    const uint32_t hQ = ORBX_H(__builtin_amdgcn_alignbyte(C##i5, L##i5, 2));   /* (-2, +2) */ \
+                    /* bit 7 set: neighbour brighter than the centre by more than the threshold */          \
+                    const uint32_t br = (ORBX_B(hU) | ORBX_B(hD)) & (ORBX_B(hL) | ORBX_B(hR)) &             \
+                                        (ORBX_B(hA) | ORBX_B(hB)) & (ORBX_B(hP) | ORBX_B(hQ));              \
                     /* bit 7 clear: neighbour darker than the centre by more than the threshold (or by exactly it) */ \
-                    const uint32_t eU = __builtin_amdgcn_lerp(hU, nZ, 0x01010101u), eD = __builtin_amdgcn_lerp(hD, nZ, 0x01010101u); \
-                    const uint32_t eL = __builtin_amdgcn_lerp(hL, nZ, 0x01010101u), eR = __builtin_amdgcn_lerp(hR, nZ, 0x01010101u); \
-                    const uint32_t F = (((bU | bD) & (bL | bR)) | ~((eU & eD) | (eL & eR))) & valid;        \
+                    const uint32_t nd = (ORBX_E(hU) & ORBX_E(hD)) | (ORBX_E(hL) & ORBX_E(hR)) |             \
+                                        (ORBX_E(hA) & ORBX_E(hB)) | (ORBX_E(hP) & ORBX_E(hQ));              \
+                    const uint32_t F = (br | ~nd) & valid;                                                  \
                     /* the four flag bits (7, 15, 23, 31) gathered into one nibble */                       \
                     mask = (mask << 4) | (((F >> 7) * 0x00204081u) >> 21 & 15u);                            \
                     c += PD;                                                                                \
-                    a0 = c[3 * PD];                                                                         \
+                    C##i0 = c[3 * PD]; L##i0 = c[3 * PD + dl]; R##i0 = c[3 * PD + dr];                      \
                 }
                 for (int r = 0; r < rows; r += 7) {
-                    ORBX_FAST_ROW4(w0, w1, w2, w3, w4, w5, w6, r + 0)
-                    ORBX_FAST_ROW4(w1, w2, w3, w4, w5, w6, w0, r + 1)
-                    ORBX_FAST_ROW4(w2, w3, w4, w5, w6, w0, w1, r + 2)
-                    ORBX_FAST_ROW4(w3, w4, w5, w6, w0, w1, w2, r + 3)
-                    ORBX_FAST_ROW4(w4, w5, w6, w0, w1, w2, w3, r + 4)
-                    ORBX_FAST_ROW4(w5, w6, w0, w1, w2, w3, w4, r + 5)
-                    ORBX_FAST_ROW4(w6, w0, w1, w2, w3, w4, w5, r + 6)
+                    ORBX_FAST_ROW4(0, 1, 2, 3, 4, 5, 6, r + 0)
+                    ORBX_FAST_ROW4(1, 2, 3, 4, 5, 6, 0, r + 1)
+                    ORBX_FAST_ROW4(2, 3, 4, 5, 6, 0, 1, r + 2)
+                    ORBX_FAST_ROW4(3, 4, 5, 6, 0, 1, 2, r + 3)
+                    ORBX_FAST_ROW4(4, 5, 6, 0, 1, 2, 3, r + 4)
+                    ORBX_FAST_ROW4(5, 6, 0, 1, 2, 3, 4, r + 5)
+                    ORBX_FAST_ROW4(6, 0, 1, 2, 3, 4, 5, r + 6)
                 }
+#undef ORBX_H
+#undef ORBX_B
+#undef ORBX_E
 #undef ORBX_FAST_ROW4
                 // keep the rows inside the lane's band / the cell: the first `valid` rows of the chunk
                 const int nvalid = min(yEnd - yc, rows);
@@ -546,6 +585,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     }
     __syncthreads();
     ORBX_STAMP(1);   // quick reject
+    ORBX_FAST_PHASE_END(2);
     const int nQueue = s_nQueue;
     const int lane = tid & 63, waveBase = tid & ~63;
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
@@ -574,6 +614,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     }
     __syncthreads();
     ORBX_STAMP(2);   // arc strength + compaction
+#ifdef ORBX_FAST_STAMPS
+    if (threadIdx.x == 0 && stampWg < kStampWgs) { g_fastStamps[stampWg][6] = (unsigned int)nQueue; g_fastStamps[stampWg][7] = (unsigned int)nMine; }
+#endif
+    ORBX_FAST_PHASE_END(3);
     // (C) 3x3 non-maximum suppression of the corners at both thresholds.  The image tile is no longer needed:
     // it receives the list of corners kept at either threshold, (verdicts << 14) | position.
     unsigned short* s_keep = reinterpret_cast<unsigned short*>(tile);
@@ -590,13 +634,11 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
             nb[0] = sp[0];         nb[1] = sp[1];         nb[2] = sp[2];
             nb[3] = sp[P];                                nb[4] = sp[P + 2];
             nb[5] = sp[2 * P];     nb[6] = sp[2 * P + 1]; nb[7] = sp[2 * P + 2];
-            const int sI = score_at(st, iniTh), sM = score_at(st, minTh);
-            bool keepI = st > iniTh, keepM = st > minTh;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                keepI = keepI && (sI > score_at(nb[k], iniTh));
-                keepM = keepM && (sM > score_at(nb[k], minTh));
-            }
+            // kept at threshold th: st > th and score(st) > score(nb) for the 8 neighbours, with score(s) = s > th ?
+            // s - 1 : 0.  A neighbour above th needs st > nb, one at or below th needs st - 1 > 0; and a neighbourhood
+            // maximum at or below th is below st anyway.  Hence: st > max(th, 1, largest neighbour).
+            const int nbMax = max(max(max(nb[0], nb[1]), max(nb[2], nb[3])), max(max(nb[4], nb[5]), max(nb[6], nb[7])));
+            const bool keepI = st > max(max(iniTh, 1), nbMax), keepM = st > max(max(minTh, 1), nbMax);
             flags = (keepI ? 1 : 0) | (keepM ? 2 : 0);
         }
         const unsigned long long bI = __ballot(flags & 1), bM = __ballot(flags & 2), bK = bI | bM;
@@ -616,6 +658,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     }
     __syncthreads();
     ORBX_STAMP(3);   // non-maximum suppression
+    ORBX_FAST_PHASE_END(4);
     const bool useIni = s_nIni > 0;
     const int n = useIni ? s_nIni : s_nMin;
     if (n == 0) return;
@@ -1249,6 +1292,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
     ORBX_DSTAMP(0);   // patch load
+    ORBX_DESC_PHASE_END(1);
 
     // ---- orientation: m10 = sum u*I, m01 = sum v*I over the radius-15 disc ----
     // item = (row v, group of 4 columns u0..u0+3, u0 = 4g - 15): the 4 pixels come as one byte
@@ -1278,6 +1322,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     ORBX_DSTAMP(1);   // orientation
+    ORBX_DESC_PHASE_END(2);
 
     // ---- separable 7-tap blur of the 37x37 core with the dot-product instructions ----
     // horizontal: item = (pair of raw rows 2 rp, 2 rp + 1; 8 output columns c0..c0+7).  The 14 source bytes of a row
@@ -1315,6 +1360,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
     ORBX_DSTAMP(2);   // horizontal blur
+    ORBX_DESC_PHASE_END(3);
     // vertical: item = (column c, 8 output rows r0..r0+7): 14 row sums = 7 packed pairs, four
     // v_dot2_u32_u16 per output; odd rows use the weight pairs shifted by one tap.  The blurred core is stored
     // transposed as well, blurT[c][r]: an item's 8 outputs are 8 consecutive bytes, one 8-byte store.
@@ -1343,6 +1389,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
     ORBX_DSTAMP(3);   // vertical blur
+    ORBX_DESC_PHASE_END(4);
 
     if (!active) return;
     // ---- steered BRIEF: lane handles comparisons 4*lane .. 4*lane+3 ----
@@ -1735,16 +1782,18 @@ static orbx_status ensure_geometry(orbx_extractor* ex, int w, int h) {
     return setup_geometry(ex, w, h);
 }
 
-// Enqueues every kernel of one batch.  Level 0 of each pyramid slab must already hold the image.
+// Enqueues every kernel of one batch.  Level 0 of each pyramid slab must already hold the image; the candidate
+// counters are cleared here unless the caller's copy kernel has done it (countersCleared).
 static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1, const orbx_rect* dyn, int ndyn,
-                                 orbx_keypoint* d_kps, uint8_t* d_desc, int capacity, int* d_counts, hipStream_t st) {
+                                 orbx_keypoint* d_kps, uint8_t* d_desc, int capacity, int* d_counts, hipStream_t st,
+                                 bool countersCleared = false) {
     const OrbxFrameGeo& g = ex->geo;
     const int nl = g.nlevels;
     ORBX_REQUIRE(ndyn >= 0 && ndyn <= kOrbxMaxRects, "at most %d dynamic rectangles", kOrbxMaxRects);
     if (ndyn > 0) ORBX_HIP_TRY(hipMemcpyAsync(ex->d_rects, dyn, ndyn * sizeof(orbx_rect), hipMemcpyHostToDevice, st));
     // the only per-batch state that must start at zero; the quadtree writes every keypoint count and
     // the error record is cleared when it is read (orbx_extract_status)
-    ORBX_HIP_TRY(hipMemsetAsync(ex->d_candCount, 0, (size_t)nf * nl * sizeof(int), st));
+    if (!countersCleared) ORBX_HIP_TRY(hipMemsetAsync(ex->d_candCount, 0, (size_t)nf * nl * sizeof(int), st));
     if (ex->timing && ex->evUsed + kTimedStages + 1 > 4096 * (size_t)(kTimedStages + 1)) resolve_timing(ex);
     mark(ex, st);   // end of copy-in (its start is marked by the caller)
     for (int l = 1; l < nl; ++l) {
@@ -1796,8 +1845,8 @@ extern "C" orbx_status orbx_extract_batch_device(orbx_extractor* ex, const uint8
     const int aligned16 = ((((uintptr_t)d_images) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
     mark(ex, st);
     hipLaunchKernelGGL(k_copy_level0, grid, dim3(256), 0, st, ex->d_geo, d_images, (long long)row_stride,
-                       (long long)frame_stride, ex->d_pyr, ex->geo.pyrBytes, aligned16, chunksPerRow);
-    return enqueue_batch(ex, n_frames, lap0, lap1, dyn_host, ndyn, d_keypoints, d_descriptors, capacity, d_counts, st);
+                       (long long)frame_stride, ex->d_pyr, ex->geo.pyrBytes, aligned16, chunksPerRow, ex->d_candCount);
+    return enqueue_batch(ex, n_frames, lap0, lap1, dyn_host, ndyn, d_keypoints, d_descriptors, capacity, d_counts, st, true);
 }
 
 extern "C" orbx_status orbx_extract_batch_staged_device(orbx_extractor* ex, orbx_stager* stager, const uint8_t* d_src,

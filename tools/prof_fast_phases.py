@@ -33,6 +33,7 @@ print(f"{w}x{h}, {B} frames per launch, {n // iters} workgroups per launch; mean
 for k, nm in enumerate(names):
     print(f"  {nm:28s} {v[k] / n:9.0f} cycles  {100.0 * v[k] / tot:5.1f} %")
 print(f"  {'total':28s} {tot / n:9.0f} cycles")
+print(f"  survivors of the quick reject per workgroup: {v[5] / n:.1f}; corners found by wave 0 (of 2): {v[6] / n:.1f}")
 L.orbx_debug_desc_stamps(buf, 1)
 v = list(buf)
 n = v[7]
