@@ -52,6 +52,10 @@ extern "C" int orbx_device_count(void) {
 __constant__ __align__(16) signed char c_pattern[1024] = {
 #include "orb_pattern.inc"
 };
+// the same offsets as binary32 (the steered tests rotate them in float): a lane's 8 points are 4 x 16 bytes
+__constant__ __align__(16) float c_patternF[1024] = {
+#include "orb_pattern.inc"
+};
 // umax[v]: half width of row v of the radius-15 disc (ORBextractor.cc:520-535)
 __constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
@@ -376,9 +380,10 @@ extern "C" int orbx_debug_desc_stamps(unsigned long long* out8, int reset) {
 #define ORBX_FAST_PHASE_END(n) do {} while (0)
 #endif
 #ifdef ORBX_DESC_STOP
-#define ORBX_DESC_PHASE_END(n) do { if (ORBX_DESC_STOP == (n)) return; } while (0)
+// (the value keeps what the phases so far have produced alive: without a consumer the compiler drops them)
+#define ORBX_DESC_PHASE_END(n, value) do { if (ORBX_DESC_STOP == (n)) { if (active) outDesc[((long long)frame * capacity + kp.slot) * 32 + (lane & 31)] = (uint8_t)(value); return; } } while (0)
 #else
-#define ORBX_DESC_PHASE_END(n) do {} while (0)
+#define ORBX_DESC_PHASE_END(n, value) do {} while (0)
 #endif
 
 // kP = LDS tile pitch known at compile time (row steps and the 3-row look-ahead become
@@ -1126,11 +1131,11 @@ __global__ __launch_bounds__(kLayThreads) void k_layout(const OrbxFrameGeo* __re
 //   7x7 Gaussian (8.8 fixed point, taps 18 34 48 56 48 34 18) on the 37x37 core
 //   256 steered comparisons -> 32 bytes
 // ======================================================================================
-constexpr int kDescWaves = 4;
+constexpr int kDescWaves = 1;     // waves (= keypoints) per workgroup
 constexpr int kRawR = 21, kRawW = 43, kRawP = 48;   // raw rows start at a 4-byte aligned column (at most 3 + 43 bytes)
 constexpr int kBlurR = 18, kBlurW = 37, kBlurP = 40;
 // transposed row sums: one dword = the sums of a row pair; an odd pitch (in dwords) spreads the columns over the banks
-constexpr int kHorTPD = 23;
+constexpr int kHorTPD = 25;
 
 __device__ __forceinline__ int reflect101_dev(int p, int n) {
     if (n == 1) return 0;
@@ -1216,6 +1221,18 @@ constexpr OrientWeights make_orient_weights() {
 }
 __constant__ OrientWeights c_orientW = make_orient_weights();
 
+// Sum of a value over the 64 lanes of the wave, returned in every lane (as a scalar): four cross-lane adds inside the
+// rows of 16 lanes, two row broadcasts, one read of lane 63 -- data-parallel-primitive moves, no LDS round trips.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror: every lane holds its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo* __restrict__ geo,
                                                               const uint8_t* __restrict__ pyr, long long frameStride,
                                                               const OrbxLevelKp* __restrict__ levelKps,
@@ -1223,9 +1240,10 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
                                                               orbx_keypoint* __restrict__ outKps,
                                                               uint8_t* __restrict__ outDesc, int capacity,
                                                               const uint8_t* __restrict__ kpLevel) {
-    // Per wave: the raw patch (later the blurred core) and the transposed row sums.  Nothing is shared between the
-    // waves of a workgroup, and the kernel's speed follows the number of resident waves, i.e. this footprint
-    // (5.5 KB per keypoint: 7 workgroups per CU).
+    // Per wave: the raw patch (later the blurred core) and the transposed row sums.  Nothing is shared between
+    // waves, so a workgroup is ONE wave: a finished keypoint frees its 5.8 KB at once instead of waiting for the
+    // slowest wave of a larger group (measured per 64 frames of 752 x 480: 109 us with 8 waves per workgroup, 98
+    // with 4, 95 with 2, 91 with 1).
     // (+ one row: the horizontal pass works on row pairs and the last pair's second row is read, never used)
     __shared__ __align__(16) uint8_t s_raw[kDescWaves][(kRawW + 1) * kRawP + 16];   // + the dword the last row's window may touch
     __shared__ __align__(16) uint32_t s_hor[kDescWaves][kBlurW * kHorTPD];   // transposed row sums: 37 columns x 22 row pairs
@@ -1292,7 +1310,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
     ORBX_DSTAMP(0);   // patch load
-    ORBX_DESC_PHASE_END(1);
+    ORBX_DESC_PHASE_END(1, rawBase[lane * 29]);
 
     // ---- orientation: m10 = sum u*I, m01 = sum v*I over the radius-15 disc ----
     // item = (row v, group of 4 columns u0..u0+3, u0 = 4g - 15): the 4 pixels come as one byte
@@ -1315,14 +1333,11 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
             m01 += v * sumI;
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        m10 += __shfl_xor(m10, off);
-        m01 += __shfl_xor(m01, off);
-    }
+    m10 = wave_sum_i32(m10);
+    m01 = wave_sum_i32(m01);
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     ORBX_DSTAMP(1);   // orientation
-    ORBX_DESC_PHASE_END(2);
+    ORBX_DESC_PHASE_END(2, rawBase[lane * 29] + (int)angle);
 
     // ---- separable 7-tap blur of the 37x37 core with the dot-product instructions ----
     // horizontal: item = (pair of raw rows 2 rp, 2 rp + 1; 8 output columns c0..c0+7).  The 14 source bytes of a row
@@ -1360,7 +1375,7 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
     ORBX_DSTAMP(2);   // horizontal blur
-    ORBX_DESC_PHASE_END(3);
+    ORBX_DESC_PHASE_END(3, hor[lane * 11] + (int)angle);
     // vertical: item = (column c, 8 output rows r0..r0+7): 14 row sums = 7 packed pairs, four
     // v_dot2_u32_u16 per output; odd rows use the weight pairs shifted by one tap.  The blurred core is stored
     // transposed as well, blurT[c][r]: an item's 8 outputs are 8 consecutive bytes, one 8-byte store.
@@ -1389,27 +1404,36 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
     ORBX_DSTAMP(3);   // vertical blur
-    ORBX_DESC_PHASE_END(4);
+    ORBX_DESC_PHASE_END(4, blur[lane * 23] + (int)angle);
 
     if (!active) return;
     // ---- steered BRIEF: lane handles comparisons 4*lane .. 4*lane+3 ----
     const float deg2rad = (float)(3.14159265358979323846 / 180.f);
     float a, b;
     sincos_f32(__fmul_rn(angle, deg2rad), &b, &a);
-    // the lane's 8 sample points = 16 consecutive signed bytes of the pattern table
-    const uint4 pat4 = *reinterpret_cast<const uint4*>(c_pattern + 16 * lane);
-    const uint32_t pat[4] = {pat4.x, pat4.y, pat4.z, pat4.w};
+    // the lane's 8 sample points = 16 consecutive floats of the pattern table.  Both rotated coordinates of a point
+    // come from packed binary32 operations (each product and sum rounded on its own, as in the scalar reference), and
+    // adding 1.5 * 2^23 + 18 rounds to the nearest-even integer and leaves (coordinate + 18) in the low mantissa bits.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const float4* patp = reinterpret_cast<const float4*>(c_patternF + 16 * lane);
+    const float4 pq[4] = {patp[0], patp[1], patp[2], patp[3]};
+    const f2 ba = {b, a}, anb = {a, -b};
+    const float magic = 12582912.0f + (float)kBlurR;
     uint32_t nib = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+        const float pts[4] = {pq[j].x, pq[j].y, pq[j].z, pq[j].w};
         int t[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const uint32_t w = pat[j] >> (16 * e);
-            const float px = (float)(int)(signed char)(w & 255u), py = (float)(int)(signed char)((w >> 8) & 255u);
-            const int ry = __float2int_rn(__fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a)));
-            const int rx = __float2int_rn(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b)));
-            t[e] = blur[(kBlurR + rx) * kBlurP + kBlurR + ry];     // transposed core
+            const float px = pts[2 * e], py = pts[2 * e + 1];
+            const f2 u = f2{px, px} * ba;                 // (px b, px a)
+            const f2 w = f2{py, py} * anb;                // (py a, -(py b)): the sign change is exact
+            const f2 r = u + w;                           // (ry, rx) = (px b + py a, px a - py b)
+            // (scalar adds on purpose: with the sum written as a 2-vector this compiler folded both lanes into one)
+            const float my = r[0] + magic, mx = r[1] + magic;
+            const uint32_t iy = __builtin_bit_cast(uint32_t, my) & 0xFFFFu, ix = __builtin_bit_cast(uint32_t, mx) & 0xFFFFu;
+            t[e] = blur[ix * kBlurP + iy];                // transposed core: [kBlurR + rx][kBlurR + ry]
         }
         nib |= (uint32_t)(t[0] < t[1]) << j;
     }

@@ -14,6 +14,6 @@ for v in f1 f2 f3 f4 d1 d2 d3 d4 p0; do
     p0) unset ORBX_LIB ;;
   esac
   echo $v
-  timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $O/$v -o p -- python3 $R/tools/prof_extract.py 64 1 > /dev/null 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAVES SQ_ACTIVE_INST_LDS --output-format csv -d $O/$v -o p -- python3 $R/tools/prof_extract.py 64 1 > /dev/null 2>&1
 done
 echo done
