@@ -1201,25 +1201,71 @@ __device__ __forceinline__ void sincos_f32(float xf, float* s_out, float* c_out)
     *c_out = (float)c;
 }
 
-// Weight bytes of the orientation disc: entry [|v| * 8 + g] = { (u + 15) for the 4 columns
-// u = 4g - 15 .. 4g - 12 that satisfy |u| <= umax[|v|] (else 0), 1 for the same columns (else 0) }.
-struct alignas(8) OrientWeights { uint32_t w[256]; };
+// Weight bytes of the orientation disc: entry [|v| * 4 + g] covers the 8 columns u = 8g - 15 .. 8g - 8 of row v as
+// { (u + 15) of the first 4 columns, 1 for the same columns, (u + 15) of the last 4, 1 for those }, a weight being 0
+// where |u| > umax[|v|] (outside the disc; u = 16 of the last group never is inside).
+struct alignas(16) OrientWeights { uint32_t w[256]; };
 constexpr OrientWeights make_orient_weights() {
     OrientWeights t{};
     const int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};   // ORBextractor.cc:520-535
     for (int av = 0; av < 16; ++av)
-        for (int g = 0; g < 8; ++g) {
-            uint32_t wu = 0, w1 = 0;
-            for (int k = 0; k < 4; ++k) {
-                const int u = 4 * g - 15 + k, au = u < 0 ? -u : u;
-                if (au <= umax[av]) { wu |= (uint32_t)(u + 15) << (8 * k); w1 |= 1u << (8 * k); }
+        for (int g = 0; g < 4; ++g)
+            for (int half = 0; half < 2; ++half) {
+                uint32_t wu = 0, w1 = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const int u = 8 * g + 4 * half - 15 + k, au = u < 0 ? -u : u;
+                    if (au <= umax[av]) { wu |= (uint32_t)(u + 15) << (8 * k); w1 |= 1u << (8 * k); }
+                }
+                t.w[4 * (av * 4 + g) + 2 * half] = wu;
+                t.w[4 * (av * 4 + g) + 2 * half + 1] = w1;
             }
-            t.w[2 * (av * 8 + g)] = wu;
-            t.w[2 * (av * 8 + g) + 1] = w1;
-        }
     return t;
 }
 __constant__ OrientWeights c_orientW = make_orient_weights();
+
+// Horizontal 7-tap pass of the blur (taps 18 34 48 56 48 34 18) over the raw patch rows of one keypoint.
+// item = (pair of raw rows 2 rp, 2 rp + 1; 8 output columns c0 .. c0 + 7).  The 20 source bytes of a row that the 8
+// outputs touch are fetched as two 8-byte reads and one dword (c0 is a multiple of 8, so the reads are aligned).
+// Output k needs bytes OX + k .. OX + k + 6 of them; instead of shifting the data into place, the TAPS are shifted: for
+// every byte offset 0..3 inside a dword there is a set of 2 or 3 weight dwords (zero where no tap falls), and the
+// output is 2 or 3 v_dot4_u32_u8 over the aligned source dwords -- 20 dot products per row and no byte shuffles.
+// The row sums are stored TRANSPOSED, horT[c][rp] = (sum of row 2 rp) | (sum of row 2 rp + 1) << 16, so that the
+// vertical pass reads consecutive rows as packed 16-bit pairs; one dword store per column and row pair.
+__device__ __forceinline__ constexpr uint32_t hblur_weight(int byteOffset, int dword) {
+    const uint32_t taps[7] = {18u, 34u, 48u, 56u, 48u, 34u, 18u};
+    uint32_t w = 0;
+    for (int b = 0; b < 4; ++b) {
+        const int tap = dword * 4 + b - byteOffset;
+        if (tap >= 0 && tap < 7) w |= taps[tap] << (8 * b);
+    }
+    return w;
+}
+template <int OX>
+__device__ __forceinline__ void hblur_rows(const uint8_t* __restrict__ rawBase, uint32_t* __restrict__ hor, int lane) {
+    constexpr int kRowPairs = (kRawW + 1) / 2;       // 22
+    for (int i = lane; i < kRowPairs * 5; i += 64) {
+        const int rp = i / 5, j = i - rp * 5, c0 = 8 * j;
+        uint32_t sums[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint8_t* rowb = rawBase + (2 * rp + h) * kRawP + c0;     // 8-byte aligned
+            const uint2 q0 = *reinterpret_cast<const uint2*>(rowb), q1 = *reinterpret_cast<const uint2*>(rowb + 8);
+            const uint32_t D[5] = {q0.x, q0.y, q1.x, q1.y, *reinterpret_cast<const uint32_t*>(rowb + 16)};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int t = OX + k, m0 = t >> 2, r = t & 3;
+                uint32_t s = __builtin_amdgcn_udot4(D[m0], hblur_weight(r, 0), 0u, false);
+                s = __builtin_amdgcn_udot4(D[m0 + 1], hblur_weight(r, 1), s, false);
+                if (r >= 2) s = __builtin_amdgcn_udot4(D[m0 + 2], hblur_weight(r, 2), s, false);
+                sums[h][k] = s;
+            }
+        }
+        uint32_t* dst = hor + c0 * kHorTPD + rp;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (c0 + k < kBlurW) dst[k * kHorTPD] = sums[0][k] | (sums[1][k] << 16);     // a row sum is < 65536
+    }
+}
 
 // Sum of a value over the 64 lanes of the wave, returned in every lane (as a scalar): four cross-lane adds inside the
 // rows of 16 lanes, two row broadcasts, one read of lane 63 -- data-parallel-primitive moves, no LDS round trips.
@@ -1313,22 +1359,23 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     ORBX_DESC_PHASE_END(1, rawBase[lane * 29]);
 
     // ---- orientation: m10 = sum u*I, m01 = sum v*I over the radius-15 disc ----
-    // item = (row v, group of 4 columns u0..u0+3, u0 = 4g - 15): the 4 pixels come as one byte
-    // window of two dwords; sum((u + 15) * I) and sum(I) over the columns inside the disc are two
-    // v_dot4_u32_u8 against the row's weight bytes (zero outside the disc).
+    // item = (row v, group of 8 columns u0 .. u0 + 7, u0 = 8g - 15): the 8 pixels come as two byte windows cut out of
+    // three dwords; sum((u + 15) * I) and sum(I) over the columns inside the disc are v_dot4_u32_u8 against the
+    // row's weight bytes (zero outside the disc).
     int m10 = 0, m01 = 0;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < 2; ++it) {
         const int i = lane + 64 * it;
-        if (i < 31 * 8) {
-            const int row = i >> 3, g = i & 7;
+        if (i < 31 * 4) {
+            const int row = i >> 2, g = i & 3;
             const int v = row - 15, av = v < 0 ? -v : v;
-            const uint2 w = *reinterpret_cast<const uint2*>(&c_orientW.w[2 * (av * 8 + g)]);   // 1 KB table, cache resident
-            const int b0 = ox + (kRawR - 15) + 4 * g;
+            const uint4 w = *reinterpret_cast<const uint4*>(&c_orientW.w[4 * (av * 4 + g)]);   // 1 KB table, cache resident
+            const int b0 = ox + (kRawR - 15) + 8 * g;
             const uint32_t* rowp = reinterpret_cast<const uint32_t*>(rawBase + (kRawR + v) * kRawP) + (b0 >> 2);
-            const uint32_t px4 = __builtin_amdgcn_alignbyte(rowp[1], rowp[0], b0 & 3);
-            const int sumI = (int)__builtin_amdgcn_udot4(px4, w.y, 0u, false);
-            const int sumUI = (int)__builtin_amdgcn_udot4(px4, w.x, 0u, false);
+            const uint32_t d0 = rowp[0], d1 = rowp[1], d2 = rowp[2];
+            const uint32_t pa = __builtin_amdgcn_alignbyte(d1, d0, b0 & 3), pb = __builtin_amdgcn_alignbyte(d2, d1, b0 & 3);
+            const int sumI = (int)__builtin_amdgcn_udot4(pb, w.w, __builtin_amdgcn_udot4(pa, w.y, 0u, false), false);
+            const int sumUI = (int)__builtin_amdgcn_udot4(pb, w.z, __builtin_amdgcn_udot4(pa, w.x, 0u, false), false);
             m10 += sumUI - 15 * sumI;
             m01 += v * sumI;
         }
@@ -1340,38 +1387,15 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     ORBX_DESC_PHASE_END(2, rawBase[lane * 29] + (int)angle);
 
     // ---- separable 7-tap blur of the 37x37 core with the dot-product instructions ----
-    // horizontal: item = (pair of raw rows 2 rp, 2 rp + 1; 8 output columns c0..c0+7).  The 14 source bytes of a row
-    // are fetched as two 8-byte reads and one dword (the patch starts `ox` < 4 bytes into the row, so the reads are
-    // 8-byte aligned) and shifted into a 16-byte window; every output is two v_dot4_u32_u8 over byte windows of it.
-    // The row sums are stored TRANSPOSED, horT[c][rp] = (sum of row 2 rp) | (sum of row 2 rp + 1) << 16, so that the
-    // vertical pass reads consecutive rows as packed 16-bit pairs; one dword store per column and row pair.
-    const uint32_t wLo = 18u | (34u << 8) | (48u << 16) | (56u << 24);
-    const uint32_t wHi = 48u | (34u << 8) | (18u << 16);
-    constexpr int kRowPairs = (kRawW + 1) / 2;       // 22
-    for (int i = lane; active && i < kRowPairs * 5; i += 64) {
-        const int rp = i / 5, j = i - rp * 5, c0 = 8 * j;
-        uint32_t sums[2][8];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint8_t* rowb = rawBase + (2 * rp + h) * kRawP + c0;     // 8-byte aligned
-            const uint2 q0 = *reinterpret_cast<const uint2*>(rowb), q1 = *reinterpret_cast<const uint2*>(rowb + 8);
-            const uint32_t d4 = *reinterpret_cast<const uint32_t*>(rowb + 16);
-            uint32_t W[4];
-            W[0] = __builtin_amdgcn_alignbyte(q0.y, q0.x, ox); W[1] = __builtin_amdgcn_alignbyte(q1.x, q0.y, ox);
-            W[2] = __builtin_amdgcn_alignbyte(q1.y, q1.x, ox); W[3] = __builtin_amdgcn_alignbyte(d4, q1.y, ox);
-            // byte windows A[k] = bytes k .. k+3 of the 16-byte window, k = 0 .. 11
-            uint32_t A[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k)
-                A[k] = (k & 3) ? __builtin_amdgcn_alignbyte(W[(k >> 2) + 1], W[k >> 2], k & 3) : W[k >> 2];
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                sums[h][k] = __builtin_amdgcn_udot4(A[k + 4], wHi, __builtin_amdgcn_udot4(A[k], wLo, 0u, false), false);
+    // horizontal: see hblur_rows; the patch starts `ox` (0..3, the same for the whole wave) bytes into its LDS rows,
+    // and each value of ox has its own instance of the loop so that every byte position is a compile-time constant.
+    if (active) {
+        switch (ox) {
+            case 0: hblur_rows<0>(rawBase, hor, lane); break;
+            case 1: hblur_rows<1>(rawBase, hor, lane); break;
+            case 2: hblur_rows<2>(rawBase, hor, lane); break;
+            default: hblur_rows<3>(rawBase, hor, lane); break;
         }
-        uint32_t* dst = hor + c0 * kHorTPD + rp;
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (c0 + k < kBlurW) dst[k * kHorTPD] = sums[0][k] | (sums[1][k] << 16);     // a row sum is < 65536
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // this wave's own LDS region: wave order is enough
     ORBX_DSTAMP(2);   // horizontal blur
