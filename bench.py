@@ -41,6 +41,7 @@ MBF, FX = 47.90639384423901, 435.2046959714599          # EuRoC-like baseline * 
 HBM_PEAK_GBS = 8000.0                                     # MI355X HBM3E spec
 VALU_U32_PEAK = 256 * 4 * 32 * 2.4e9                      # lane-ops/s (256 CU x 4 SIMD x 32 lanes x 2.4 GHz), nominal
 VALU_XOR_BCNT_MEASURED = 49.4e12                          # lane-ops/s of the search's own instruction pair, measured
+VALU_INT_MEASURED = 37.6e12                               # lane-ops/s of any single integer / byte VALU instruction, measured
 NQ_MAP, NT_MAP = 5000, 10_000_000
 
 
@@ -299,6 +300,23 @@ def main():
             break
         except (OSError, KeyError, ValueError):
             pass
+    # VALU work of a frame, from the committed counter pass (SQ_INSTS_VALU per kernel and launch of 64 frames), against
+    # the measured integer issue rate of the chip: the bound that actually limits the extraction
+    valu = None
+    try:
+        import csv
+        with open(os.path.join(ROOT, "profiles", "r02_extract_euroc_b64_pmc_sq.csv")) as f:
+            rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
+        per_launch = {r["kernel"]: float(r["SQ_INSTS_VALU"]) for r in rows}
+        launches = {k: (NLEVELS - 1 if k == "k_resize" else 1) for k in per_launch}
+        wave_instr = sum(per_launch[k] * launches[k] for k in per_launch) / 64.0
+        ceiling = VALU_INT_MEASURED / (wave_instr * 64.0)
+        valu = {"wave_instructions_per_frame": wave_instr, "per_kernel_per_64_frames": per_launch,
+                "issue_rate_lane_ops_per_s": VALU_INT_MEASURED, "ceiling_frames_per_s": ceiling,
+                "source": "committed profile profiles/r02_extract_euroc_b64_pmc_sq.csv (SQ_INSTS_VALU; not measured by this run) and "
+                          "profiles/r02_ubench_valu_issue.txt (issue rate)"}
+    except (OSError, KeyError, ValueError):
+        pass
     fast_s = stage_ms["fast"] * 1e-3
     achieved = fast_bytes / fast_s / 1e9 if fast_s > 0 else 0.0
     frame_bytes = W * H + px + 60 * n_kp                                   # input + pyramid + keypoints/descriptors
@@ -333,6 +351,9 @@ def main():
         "stream_overlap_ratio": overlap,
     }
 
+    if valu is not None:
+        valu["frac_of_ceiling"] = value / world / valu["ceiling_frames_per_s"]
+        out["valu_issue"] = valu
     if host_path is not None:
         out["host_path"] = host_path
     # release the EuRoC buffers before the larger legs
