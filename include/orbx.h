@@ -605,6 +605,23 @@ orbx_status orbx_bow_vectors(orbx_vocabulary* voc, const uint8_t* desc, int n, i
 orbx_status orbx_distinctive_descriptors(const uint8_t* desc, const int* off, int n_points,
                                          int* best_idx, int* best_median);
 
+/* Frame::ComputeStereoFishEyeMatches (Frame.cc:1286-1338), the whole member: brute-force k = 2 search of the
+ * left descriptors [mono_left, n_left) in the right descriptors [mono_right, n_right) (Frame.cc:1290-1309), Lowe's
+ * ratio test `best < 0.7 * second` in double as the reference evaluates it (:1318), KannalaBrandt8::TriangulateMatches
+ * (KannalaBrandt8.cpp:336-401) of every match that passes with R_lr / t_lr = Frame::mRlr / mtlr (row-major 3x3, 3) and
+ * sigma = level_sigma2[octave] of the two keypoints, accepted when the depth exceeds 0.0001 (:1328).  Matches are
+ * visited in ascending left index, so a right keypoint claimed twice keeps the later left one, as in the
+ * reference.  Outputs (host): left_to_right[n_left] / right_to_left[n_right] = mvLeftToRightMatch /
+ * mvRightToLeftMatch (-1 none), depth[n_left] = mvDepth (-1 none), points3d[n_left x 3] = mvStereo3Dpoints (rows
+ * of unmatched keypoints are left untouched; may be NULL), *n_matches = nMatches.  The search runs on the GPU, the
+ * per-match triangulation (a few hundred 4x4 null vectors) on the calling thread. */
+orbx_status orbx_stereo_fisheye_matches(const orbx_keypoint* kps_left, const uint8_t* desc_left, int n_left, int mono_left,
+                                        const orbx_keypoint* kps_right, const uint8_t* desc_right, int n_right,
+                                        int mono_right, const orbx_camera_model* cam_left,
+                                        const orbx_camera_model* cam_right, const float* R_lr, const float* t_lr,
+                                        const float* level_sigma2, int n_levels, int* left_to_right, int* right_to_left,
+                                        float* depth, float* points3d, int* n_matches);
+
 /* ---- saved-map records (the source of large map-descriptor sets) ------------------------------
  * The reference writes keypoints and descriptors into its Atlas archives (System.cc:1568-1672, boost text or binary
  * archive) through two templates: serializeMatrix (include/SerializationUtils.h:76-108: cols, rows, type,

@@ -245,6 +245,28 @@ inline void ComputeStereoMatches(Extractor& left, Extractor& right, const std::v
                             mvuRight.data(), mvDepth.data()));
 }
 
+// Frame::ComputeStereoFishEyeMatches (Frame.cc:1286-1338): fills mvLeftToRightMatch / mvRightToLeftMatch / mvDepth /
+// mvStereo3Dpoints (x, y, z per left keypoint) and returns nMatches.  camLeft / camRight are KannalaBrandt8 models,
+// Rlr (row-major 3x3) / tlr = mRlr / mtlr.
+inline int ComputeStereoFishEyeMatches(const std::vector<orbx_keypoint>& mvKeys, const std::vector<uint8_t>& mDescriptors,
+                                       int monoLeft, const std::vector<orbx_keypoint>& mvKeysRight,
+                                       const std::vector<uint8_t>& mDescriptorsRight, int monoRight,
+                                       const orbx_camera_model& camLeft, const orbx_camera_model& camRight, const float* Rlr,
+                                       const float* tlr, const std::vector<float>& mvLevelSigma2,
+                                       std::vector<int>& mvLeftToRightMatch, std::vector<int>& mvRightToLeftMatch,
+                                       std::vector<float>& mvDepth, std::vector<float>& mvStereo3Dpoints) {
+    mvLeftToRightMatch.assign(mvKeys.size(), -1);
+    mvRightToLeftMatch.assign(mvKeysRight.size(), -1);
+    mvDepth.assign(mvKeys.size(), -1.f);
+    mvStereo3Dpoints.assign(3 * mvKeys.size(), 0.f);
+    int n = 0;
+    check(orbx_stereo_fisheye_matches(mvKeys.data(), mDescriptors.data(), (int)mvKeys.size(), monoLeft, mvKeysRight.data(),
+                                      mDescriptorsRight.data(), (int)mvKeysRight.size(), monoRight, &camLeft, &camRight, Rlr,
+                                      tlr, mvLevelSigma2.data(), (int)mvLevelSigma2.size(), mvLeftToRightMatch.data(),
+                                      mvRightToLeftMatch.data(), mvDepth.data(), mvStereo3Dpoints.data(), &n));
+    return n;
+}
+
 // Frame::BFmatcher.knnMatch(query, train, 2) (Frame.cc:1309).
 inline std::vector<orbx_match2> KnnMatch2(const uint8_t* query, int nq, const uint8_t* train, int64_t nt) {
     std::vector<orbx_match2> out(nq);

@@ -114,6 +114,8 @@ def lib():
         L.orc_search_for_triangulation_cameras.argtypes = ([C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]) * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_float, C.c_float] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]
         L.orc_kb8_triangulate_matches.restype = C.c_float
         L.orc_kb8_triangulate_matches.argtypes = [C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+        L.orc_stereo_fisheye_matches.restype = C.c_int
+        L.orc_stereo_fisheye_matches.argtypes = ([C.c_void_p, C.c_void_p, C.c_int, C.c_int]) * 2 + [C.c_void_p] * 9
         L.orc_camera_project.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_camera_unproject.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_epipolar_constrain.restype = C.c_int
@@ -615,6 +617,19 @@ def camera_unproject(cam_type, params, uv):
 def kb8_triangulate_matches(cam1, cam2, p1, p2, R12, t12, sigma1, sigma2):
     return float(lib().orc_kb8_triangulate_matches(_p(_f32(cam1)), _p(_f32(cam2)), float(p1[0]), float(p1[1]), float(p2[0]),
                                                    float(p2[1]), _p(_f32(R12).reshape(9)), _p(_f32(t12)), sigma1, sigma2))
+
+
+def stereo_fisheye_matches(kpsL, descL, mono_left, kpsR, descR, mono_right, cam1, cam2, Rlr, tlr, level_sigma2):
+    """Frame::ComputeStereoFishEyeMatches: (left_to_right, right_to_left, depth, points3d, nMatches)."""
+    kpsL, kpsR = np.ascontiguousarray(kpsL), np.ascontiguousarray(kpsR)
+    descL, descR = _u8(descL), _u8(descR)
+    nL, nR = len(kpsL), len(kpsR)
+    l2r, r2l = np.zeros(nL, np.int32), np.zeros(nR, np.int32)
+    depth, p3d = np.zeros(nL, np.float32), np.zeros((nL, 3), np.float32)
+    n = lib().orc_stereo_fisheye_matches(_p(kpsL), _p(descL), nL, mono_left, _p(kpsR), _p(descR), nR, mono_right,
+                                         _p(_f32(cam1)), _p(_f32(cam2)), _p(_f32(Rlr).reshape(9)), _p(_f32(tlr)),
+                                         _p(_f32(level_sigma2)), _p(l2r), _p(r2l), _p(depth), _p(p3d))
+    return l2r, r2l, depth, p3d, n
 
 
 def epipolar_constrain(type1, cam1, type2, cam2, p1, p2, R12, t12, sigma1, sigma2):

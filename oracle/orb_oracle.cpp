@@ -1752,6 +1752,41 @@ float orc_kb8_triangulate_matches(const float* cam1, const float* cam2, float u1
     for (int k = 0; k < 8; ++k) { c1.p[k] = cam1[k]; c2.p[k] = cam2[k]; }
     return orbx_gates::triangulate_matches(c1, c2, u1, v1, u2, v2, R12, t12, sigmaLevel, unc);
 }
+// Frame::ComputeStereoFishEyeMatches (Frame.cc:1286-1338): knnMatch(k = 2) of the lapping-area descriptors, ratio 0.7,
+// TriangulateMatches, depth > 0.0001.  Returns nMatches.
+int orc_stereo_fisheye_matches(const void* kL_, const uint8_t* dL, int nL, int monoL, const void* kR_,
+                               const uint8_t* dR, int nR, int monoR, const float* cam1, const float* cam2, const float* Rlr,
+                               const float* tlr, const float* sigma2, int* l2r, int* r2l, float* depth, float* p3d) {
+    const KeyPt* kL = (const KeyPt*)kL_;
+    const KeyPt* kR = (const KeyPt*)kR_;
+    for (int i = 0; i < nL; ++i) { l2r[i] = -1; depth[i] = -1.f; }
+    for (int i = 0; i < nR; ++i) r2l[i] = -1;
+    orbx_gates::Camera c1, c2;
+    c1.type = c2.type = orbx_gates::kKannalaBrandt8;
+    for (int k = 0; k < 8; ++k) { c1.p[k] = cam1[k]; c2.p[k] = cam2[k]; }
+    int nMatches = 0;
+    for (int q = monoL; q < nL; ++q) {
+        // the two nearest right descriptors, the lower index first among equals (BFMatcher's order)
+        int best = INT32_MAX, second = INT32_MAX, bestIdx = -1, secondIdx = -1;
+        for (int t = monoR; t < nR; ++t) {
+            int d = 0;
+            for (int k = 0; k < 32; ++k) d += __builtin_popcount((unsigned)(dL[(size_t)q * 32 + k] ^ dR[(size_t)t * 32 + k]));
+            if (d < best) { second = best; secondIdx = bestIdx; best = d; bestIdx = t; }
+            else if (d < second) { second = d; secondIdx = t; }
+        }
+        if (secondIdx < 0) continue;
+        if (!((float)best < (float)second * 0.7)) continue;
+        orbx_gates::Vec3 P{0.f, 0.f, 0.f};
+        const float z = orbx_gates::triangulate_matches(c1, c2, kL[q].x, kL[q].y, kR[bestIdx].x, kR[bestIdx].y, Rlr, tlr,
+                                                        sigma2[kL[q].octave], sigma2[kR[bestIdx].octave], &P);
+        if (z > 0.0001f) {
+            l2r[q] = bestIdx; r2l[bestIdx] = q; depth[q] = z;
+            p3d[3 * q] = P.x; p3d[3 * q + 1] = P.y; p3d[3 * q + 2] = P.z;
+            ++nMatches;
+        }
+    }
+    return nMatches;
+}
 void orc_camera_project(int type, const float* params, const float* xyz, float* uv) {
     orbx_gates::Camera c; c.type = type;
     for (int k = 0; k < 8; ++k) c.p[k] = params[k];

@@ -107,9 +107,10 @@ inline void null_vector4(const float A[4][4], float out[4]) {
     for (int i = 0; i < 4; ++i) out[i] = V[i][best];
 }
 
-// KannalaBrandt8::TriangulateMatches: the depth in camera 1 of the triangulated point, or a negative code.
+// KannalaBrandt8::TriangulateMatches: the depth in camera 1 of the triangulated point, or a negative code; the point
+// itself (camera-1 coordinates) through p3D when the depth is positive.
 inline float triangulate_matches(const Camera& c1, const Camera& c2, float u1, float v1, float u2, float v2,
-                                 const float* R12, const float* t12, float sigmaLevel, float unc) {
+                                 const float* R12, const float* t12, float sigmaLevel, float unc, Vec3* p3D = nullptr) {
     const Vec3 r1 = unproject(c1, u1, v1), r2 = unproject(c2, u2, v2);
     const Vec3 r21 = mat_vec(R12, r2);
     const float n1 = sqrtf(r1.x * r1.x + r1.y * r1.y + r1.z * r1.z), n21 = sqrtf(r21.x * r21.x + r21.y * r21.y + r21.z * r21.z);
@@ -145,6 +146,7 @@ inline float triangulate_matches(const Camera& c1, const Camera& c2, float u1, f
     project(c2, x3D2, &pu, &pv);
     const float errX2 = pu - u2, errY2 = pv - v2;
     if ((errX2 * errX2 + errY2 * errY2) > 5.991 * unc) return -5;
+    if (p3D) *p3D = x3D;
     return z1;
 }
 

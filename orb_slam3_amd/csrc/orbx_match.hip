@@ -1209,6 +1209,52 @@ extern "C" orbx_status orbx_hamming_knn2(const uint8_t* query, int n_query, cons
     return ORBX_OK;
 }
 
+extern "C" orbx_status orbx_stereo_fisheye_matches(const orbx_keypoint* kps_left, const uint8_t* desc_left, int n_left,
+                                                   int mono_left, const orbx_keypoint* kps_right,
+                                                   const uint8_t* desc_right, int n_right, int mono_right,
+                                                   const orbx_camera_model* cam_left, const orbx_camera_model* cam_right,
+                                                   const float* R_lr, const float* t_lr, const float* level_sigma2,
+                                                   int n_levels, int* left_to_right, int* right_to_left, float* depth,
+                                                   float* points3d, int* n_matches) {
+    ORBX_REQUIRE(n_left >= 0 && n_right >= 0 && mono_left >= 0 && mono_left <= n_left && mono_right >= 0 && mono_right <= n_right,
+                 "bad keypoint counts / lapping indices");
+    ORBX_REQUIRE(n_matches && (n_left == 0 || (left_to_right && depth)) && (n_right == 0 || right_to_left), "null argument");
+    for (int i = 0; i < n_left; ++i) { left_to_right[i] = -1; depth[i] = -1.f; }
+    for (int i = 0; i < n_right; ++i) right_to_left[i] = -1;
+    *n_matches = 0;
+    const int nq = n_left - mono_left, nt = n_right - mono_right;
+    if (nq == 0 || nt == 0) return ORBX_OK;
+    ORBX_REQUIRE(kps_left && desc_left && kps_right && desc_right && cam_left && cam_right && R_lr && t_lr && level_sigma2 &&
+                 n_levels >= 1, "null argument");
+    std::vector<orbx_match2> m((size_t)nq);
+    orbx_status s = orbx_hamming_knn2(desc_left + (size_t)mono_left * 32, nq, desc_right + (size_t)mono_right * 32, nt, m.data());
+    if (s != ORBX_OK) return s;
+    orbx_gates::Camera c1, c2;
+    c1.type = cam_left->type; c2.type = cam_right->type;
+    for (int k = 0; k < 8; ++k) { c1.p[k] = cam_left->params[k]; c2.p[k] = cam_right->params[k]; }
+    int nm = 0;
+    for (int i = 0; i < nq; ++i) {
+        if (m[i].idx1 < 0) continue;                                            // fewer than two neighbours (:1318)
+        if (!((double)(float)m[i].dist0 < (double)(float)m[i].dist1 * 0.7)) continue;
+        const int iL = i + mono_left, iR = m[i].idx0 + mono_right;
+        const orbx_keypoint& a = kps_left[iL];
+        const orbx_keypoint& b = kps_right[iR];
+        ORBX_REQUIRE(a.octave >= 0 && a.octave < n_levels && b.octave >= 0 && b.octave < n_levels, "keypoint level outside the sigma table");
+        orbx_gates::Vec3 P{0.f, 0.f, 0.f};
+        const float z = orbx_gates::triangulate_matches(c1, c2, a.x, a.y, b.x, b.y, R_lr, t_lr, level_sigma2[a.octave],
+                                                        level_sigma2[b.octave], &P);
+        if (z > 0.0001f) {
+            left_to_right[iL] = iR;
+            right_to_left[iR] = iL;
+            depth[iL] = z;
+            if (points3d) { points3d[3 * iL] = P.x; points3d[3 * iL + 1] = P.y; points3d[3 * iL + 2] = P.z; }
+            ++nm;
+        }
+    }
+    *n_matches = nm;
+    return ORBX_OK;
+}
+
 struct orbx_frame {
     int device = -1;       // where the features live; searches switch the calling thread to it
     int n = 0;

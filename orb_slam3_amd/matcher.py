@@ -574,6 +574,25 @@ def knn2_merge_device(d_parts, out=None):
     return out
 
 
+def compute_stereo_fisheye_matches(kps_left, desc_left, mono_left, kps_right, desc_right, mono_right, cam_left: "CameraModel",
+                                   cam_right: "CameraModel", R_lr, t_lr, level_sigma2):
+    """Frame::ComputeStereoFishEyeMatches (Frame.cc:1286-1338): returns (mvLeftToRightMatch, mvRightToLeftMatch, mvDepth,
+    mvStereo3Dpoints, nMatches).  cam_* are KannalaBrandt8 models; R_lr / t_lr = mRlr / mtlr."""
+    kps_left, kps_right = np.ascontiguousarray(kps_left, KP_DTYPE), np.ascontiguousarray(kps_right, KP_DTYPE)
+    desc_left, desc_right = np.ascontiguousarray(desc_left, np.uint8), np.ascontiguousarray(desc_right, np.uint8)
+    R = np.ascontiguousarray(R_lr, np.float32).reshape(9)
+    t = np.ascontiguousarray(t_lr, np.float32).reshape(3)
+    sig = np.ascontiguousarray(level_sigma2, np.float32)
+    nL, nR = len(kps_left), len(kps_right)
+    l2r, r2l = np.empty(nL, np.int32), np.empty(nR, np.int32)
+    depth, p3d = np.empty(nL, np.float32), np.zeros((nL, 3), np.float32)
+    n = C.c_int(0)
+    check(lib().orbx_stereo_fisheye_matches(ptr(kps_left), ptr(desc_left), nL, int(mono_left), ptr(kps_right), ptr(desc_right), nR,
+                                            int(mono_right), C.byref(cam_left), C.byref(cam_right), ptr(R), ptr(t), ptr(sig),
+                                            len(sig), ptr(l2r), ptr(r2l), ptr(depth), ptr(p3d), C.byref(n)))
+    return l2r, r2l, depth, p3d, n.value
+
+
 def fisheye_ratio_matches(m2: np.ndarray, ratio: float = 0.7) -> np.ndarray:
     """The ratio test of Frame::ComputeStereoFishEyeMatches (Frame.cc:1316-1321):
     keeps queries with >= 2 neighbours and dist0 < dist1 * 0.7 (double arithmetic)."""

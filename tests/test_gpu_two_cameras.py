@@ -4,6 +4,8 @@ right-grid pass (ORBmatcher.cc:146-213), SearchByProjection(Cur, Last) with the 
 rotation histogram (:1879-1969), Fuse(..., bRight) (:1214-1407), SearchForTriangulation with the per-candidate
 camera pair and KannalaBrandt8::epipolarConstrain (:1099-1139).  Fixture: a 512 x 512 synthetic stereo pair run
 through the extractor with the TUM-VI lapping area.  Bar: identical assignment arrays and return values."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -326,3 +328,62 @@ def test_search_for_triangulation_cameras_single_camera_equals_existing_entry_po
     out2, nm2 = m.SearchForTriangulation(k1, d1, free, None, fv, k2, d2, free, None, fv, F12, ep, SF, sig2)
     assert (out == out2).mean() > 0.98
     assert nm > 100
+
+
+def test_compute_stereo_fisheye_matches(oracle):
+    """Frame::ComputeStereoFishEyeMatches as one call (Frame.cc:1286-1338): brute-force search of the lapping-area
+    descriptors, ratio test, KannalaBrandt8::TriangulateMatches, on a synthetic two-camera scene (3-D points seen by
+    both cameras, a fifth of them with a wrong right position, distractor descriptors, mono keypoints in front)."""
+    A = _gpu()
+    from orb_slam3_amd.matcher import CameraModel, compute_stereo_fisheye_matches
+    rng = np.random.default_rng(21)
+    n, mono_l, mono_r, extra = 600, 50, 30, 200
+    cam = np.array([190.98, 190.97, 254.93, 256.9, 0.0034, 0.0007, -0.0021, 0.0002], np.float32)
+    cam2 = np.array([190.44, 190.43, 252.6, 254.9, 0.0034, 0.0018, -0.0027, 0.0004], np.float32)
+    ang = 0.02
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], np.float32)
+    t = np.array([0.101, 0.0002, -0.001], np.float32)
+    P = np.stack([rng.uniform(-2, 2, n), rng.uniform(-2, 2, n), rng.uniform(1, 6, n)], 1).astype(np.float32)
+    Pr = (P - t) @ R                                            # x_r = R^T (x_l - t)
+    uvL = np.array([oracle.camera_project(1, cam, p) for p in P], np.float32)
+    uvR = np.array([oracle.camera_project(1, cam2, p) for p in Pr], np.float32)
+    uvR += rng.normal(0, 0.3, uvR.shape).astype(np.float32)
+    bad = rng.random(n) < 0.2
+    uvR[bad] = rng.uniform(20, 490, (int(bad.sum()), 2)).astype(np.float32)
+
+    def kps(uv, count):
+        k = np.zeros(count, A.KP_DTYPE)
+        k["x"][:len(uv)] = uv[:, 0]; k["y"][:len(uv)] = uv[:, 1]
+        k["octave"] = rng.integers(0, 8, count)
+        k["class_id"] = -1
+        return k
+    dL = synth.random_descriptors(n, 31)
+    dR = dL.copy()
+    flips = rng.integers(0, 256, (n, 12))
+    for i in range(n):
+        for b in flips[i, :rng.integers(0, 12)]:
+            dR[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    perm = rng.permutation(n + extra)                           # right keypoints in another order, with distractors
+    kR_all = kps(np.concatenate([uvR, rng.uniform(20, 490, (extra, 2)).astype(np.float32)]), n + extra)[perm]
+    dR_all = np.concatenate([dR, synth.random_descriptors(extra, 32)])[perm]
+    kL_full = np.concatenate([kps(rng.uniform(20, 490, (mono_l, 2)).astype(np.float32), mono_l), kps(uvL, n)])
+    dL_full = np.concatenate([synth.random_descriptors(mono_l, 33), dL])
+    kR_full = np.concatenate([kps(rng.uniform(20, 490, (mono_r, 2)).astype(np.float32), mono_r), kR_all])
+    dR_full = np.concatenate([synth.random_descriptors(mono_r, 34), dR_all])
+    dR_full[mono_r + 5] = dR_full[mono_r + 9]                   # two equal right descriptors: the lower index wins or the ratio fails
+    sigma2 = (np.float32(1.2) ** (2 * np.arange(8))).astype(np.float32)
+    want = oracle.stereo_fisheye_matches(kL_full, dL_full, mono_l, kR_full, dR_full, mono_r, cam, cam2, R, t, sigma2)
+    c1, c2 = CameraModel(1, (C.c_float * 8)(*cam)), CameraModel(1, (C.c_float * 8)(*cam2))
+    got = compute_stereo_fisheye_matches(kL_full, dL_full, mono_l, kR_full, dR_full, mono_r, c1, c2, R, t, sigma2)
+    assert got[4] == want[4] and 200 < got[4] < n
+    for g, w in zip(got[:3], want[:3]):
+        assert np.array_equal(g, w)
+    ok = got[0] >= 0
+    assert np.array_equal(got[3][ok], want[3][ok])
+    assert (got[0][:mono_l] == -1).all() and (got[1][:mono_r] == -1).all()
+    # the triangulated points are the scene's points (camera-1 coordinates) up to the pixel noise
+    src = np.nonzero(ok)[0] - mono_l
+    assert np.median(np.linalg.norm(got[3][ok] - P[src], axis=1) / P[src][:, 2]) < 0.05
+    # nothing to match: every output is "none"
+    e = compute_stereo_fisheye_matches(kL_full, dL_full, len(kL_full), kR_full, dR_full, mono_r, c1, c2, R, t, sigma2)
+    assert e[4] == 0 and (e[0] == -1).all() and (e[1] == -1).all() and (e[2] == -1).all()

@@ -68,3 +68,27 @@ def test_pinhole_epipolar_distance_threshold(oracle):
     for dy, sig2, expect in ((1.9, 1.0, True), (2.0, 1.0, False), (3.0, 2.9859846, True), (3.5, 2.9859846, False)):
         q = p2 + np.float32([rng.uniform(-20, 20), dy])
         assert oracle.epipolar_constrain(0, PIN, 0, PIN, p1, q, R, t, 1.0, sig2) == expect
+
+
+def test_stereo_fisheye_matches_recovers_the_scene(oracle):
+    """The oracle's Frame::ComputeStereoFishEyeMatches on exact projections of known 3-D points: every pair is matched
+    and triangulated back to its point; a right keypoint moved off its ray is rejected by the reprojection gate."""
+    rng = np.random.default_rng(5)
+    n = 60
+    cam = np.array([190.98, 190.97, 254.93, 256.9, 0.0034, 0.0007, -0.0021, 0.0002], np.float32)
+    R = np.eye(3, dtype=np.float32)
+    t = np.array([0.1, 0.0, 0.0], np.float32)
+    P = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.5, 1.5, n), rng.uniform(1, 4, n)], 1).astype(np.float32)
+    uvL = np.array([oracle.camera_project(1, cam, p) for p in P], np.float32)
+    uvR = np.array([oracle.camera_project(1, cam, p - t) for p in P], np.float32)
+    uvR[7] += np.float32(25.0)                                  # off the epipolar geometry
+    KP = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+    kL, kR = np.zeros(n, KP), np.zeros(n, KP)
+    kL["x"], kL["y"], kR["x"], kR["y"] = uvL[:, 0], uvL[:, 1], uvR[:, 0], uvR[:, 1]
+    d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sigma2 = np.ones(8, np.float32)
+    l2r, r2l, depth, p3d, nm = oracle.stereo_fisheye_matches(kL, d, 0, kR, d, 0, cam, cam, R, t, sigma2)
+    assert nm == n - 1 and l2r[7] == -1 and depth[7] == -1
+    ok = l2r >= 0
+    assert np.array_equal(l2r[ok], np.nonzero(ok)[0]) and np.array_equal(r2l[ok], np.nonzero(ok)[0])
+    assert np.allclose(p3d[ok], P[ok], rtol=2e-3, atol=2e-3) and np.allclose(depth[ok], P[ok][:, 2], rtol=2e-3)
