@@ -92,6 +92,11 @@ void orbx_extractor_destroy(orbx_extractor* ex);
 orbx_status orbx_extractor_tables(const orbx_extractor* ex, float* scale, float* inv_scale,
                                   float* sigma2, float* inv_sigma2, int* features_per_level);
 
+/* The same tables from the constructor arguments alone (ORBextractor.cc:481-512): host arithmetic, no device and
+ * no handle needed.  Any pointer may be NULL. */
+orbx_status orbx_scale_tables(int nfeatures, float scale_factor, int nlevels, float* scale, float* inv_scale,
+                              float* sigma2, float* inv_sigma2, int* features_per_level);
+
 /* Largest number of keypoints one frame can yield (>= nfeatures); size output buffers
  * with it. */
 int orbx_extractor_max_keypoints(const orbx_extractor* ex);

@@ -10,6 +10,7 @@
 #define ORBX_EXTRACTOR_HPP_
 
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -38,17 +39,21 @@ public:
     // (ORBextractor.cc:477).  The device buffers are sized lazily from the first image.
     Extractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = -1)
         : nfeatures_(nfeatures), scaleFactor_(scaleFactor), nlevels_(nlevels), iniTh_(iniThFAST), minTh_(minThFAST),
-          device_(device) {}
+          device_(device) {
+        // the tables are host arithmetic on the constructor arguments: available before any image or device exists
+        sf_.resize(nlevels_); isf_.resize(nlevels_); s2_.resize(nlevels_); is2_.resize(nlevels_);
+        check(orbx_scale_tables(nfeatures_, scaleFactor_, nlevels_, sf_.data(), isf_.data(), s2_.data(), is2_.data(), nullptr));
+    }
     ~Extractor() { if (h_) orbx_extractor_destroy(h_); }
     Extractor(const Extractor&) = delete;
     Extractor& operator=(const Extractor&) = delete;
 
     int GetLevels() const { return nlevels_; }
     float GetScaleFactor() const { return scaleFactor_; }
-    std::vector<float> GetScaleFactors() { ensure(752, 480); return sf_; }
-    std::vector<float> GetInverseScaleFactors() { ensure(752, 480); return isf_; }
-    std::vector<float> GetScaleSigmaSquares() { ensure(752, 480); return s2_; }
-    std::vector<float> GetInverseScaleSigmaSquares() { ensure(752, 480); return is2_; }
+    std::vector<float> GetScaleFactors() const { return sf_; }
+    std::vector<float> GetInverseScaleFactors() const { return isf_; }
+    std::vector<float> GetScaleSigmaSquares() const { return s2_; }
+    std::vector<float> GetInverseScaleSigmaSquares() const { return is2_; }
 
     // operator(): returns monoIndex, or -1 for an empty image (ORBextractor.cc:1271-1399).
     // keypoints / descriptors are resized to the number of keypoints (descriptors: n x 32).
@@ -69,7 +74,34 @@ public:
         return mono;
     }
 
+    // The same call with the output storage supplied by the caller: keypointStorage(capacity) / descriptorStorage(capacity)
+    // return buffers of `capacity` keypoints / capacity x 32 bytes; *n = keypoints written.  Returns monoIndex.
+    template <class KpAlloc, class DescAlloc>
+    int extract_into(const uint8_t* image, int width, int height, ptrdiff_t stride, const std::vector<int>& vLappingArea,
+                     KpAlloc keypointStorage, DescAlloc descriptorStorage, int* n) {
+        *n = 0;
+        if (!image || width <= 0 || height <= 0) return -1;
+        ensure(width, height);
+        const int cap = orbx_extractor_max_keypoints(h_);
+        int mono = 0;
+        check(orbx_extract(h_, image, width, height, stride, vLappingArea.at(0), vLappingArea.at(1),
+                           mvDynamicArea.empty() ? nullptr : mvDynamicArea.data(), (int)mvDynamicArea.size(),
+                           keypointStorage(cap), descriptorStorage(cap), cap, n, &mono));
+        return mono;
+    }
+
     orbx_extractor* handle() { return h_; }
+
+    // mvImagePyramid of the last call, copied from the device (done by operator() itself when keepPyramid is set)
+    void fetch_pyramid() {
+        mvImagePyramid.resize(nlevels_);
+        for (int l = 0; l < nlevels_; ++l) {
+            Level& L = mvImagePyramid[l];
+            check(orbx_pyramid_level(h_, 0, l, nullptr, 0, &L.width, &L.height));
+            L.pixels.resize((size_t)L.width * L.height);
+            check(orbx_pyramid_level(h_, 0, l, L.pixels.data(), L.pixels.size(), &L.width, &L.height));
+        }
+    }
 
     // public members of the reference class
     std::vector<Level> mvImagePyramid;        // filled after each call when keepPyramid is set
@@ -85,17 +117,6 @@ private:
         maxH_ = h > maxH_ ? h : maxH_;
         orbx_params p{nfeatures_, scaleFactor_, nlevels_, iniTh_, minTh_, maxW_, maxH_, 1, device_};
         check(orbx_extractor_create(&p, &h_));
-        sf_.resize(nlevels_); isf_.resize(nlevels_); s2_.resize(nlevels_); is2_.resize(nlevels_);
-        check(orbx_extractor_tables(h_, sf_.data(), isf_.data(), s2_.data(), is2_.data(), nullptr));
-    }
-    void fetch_pyramid() {
-        mvImagePyramid.resize(nlevels_);
-        for (int l = 0; l < nlevels_; ++l) {
-            Level& L = mvImagePyramid[l];
-            check(orbx_pyramid_level(h_, 0, l, nullptr, 0, &L.width, &L.height));
-            L.pixels.resize((size_t)L.width * L.height);
-            check(orbx_pyramid_level(h_, 0, l, L.pixels.data(), L.pixels.size(), &L.width, &L.height));
-        }
     }
     int nfeatures_; float scaleFactor_; int nlevels_, iniTh_, minTh_, device_;
     int maxW_ = 0, maxH_ = 0;
@@ -157,7 +178,7 @@ class ORBextractor {
 public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
-        : impl_(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) { impl_.keepPyramid = true; }
+        : impl_(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) {}
     int operator()(cv::InputArray _image, cv::InputArray /*_mask*/, std::vector<cv::KeyPoint>& _keypoints,
                    cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
         if (_image.empty()) return -1;
@@ -166,20 +187,28 @@ public:
         static_assert(sizeof(cv::KeyPoint) == sizeof(orbx_keypoint), "cv::KeyPoint layout");
         impl_.mvDynamicArea.clear();
         for (const cv::Rect2i& r : mvDynamicArea) impl_.mvDynamicArea.push_back(orbx_rect{r.x, r.y, r.width, r.height});
-        std::vector<orbx_keypoint> kps;
-        std::vector<uint8_t> desc;
-        const int mono = impl_(image.data, image.cols, image.rows, (ptrdiff_t)image.step, kps, desc, vLappingArea);
-        _keypoints.resize(kps.size());
-        if (!kps.empty()) std::memcpy((void*)_keypoints.data(), kps.data(), kps.size() * sizeof(orbx_keypoint));
-        if (kps.empty()) _descriptors.release();
-        else { _descriptors.create((int)kps.size(), 32, CV_8U); std::memcpy(_descriptors.getMat().data, desc.data(), desc.size()); }
-        mvImagePyramid.resize(impl_.mvImagePyramid.size());
-        for (size_t l = 0; l < impl_.mvImagePyramid.size(); ++l) {
-            orbx::Level& L = impl_.mvImagePyramid[l];
-            mvImagePyramid[l] = cv::Mat(L.height, L.width, CV_8UC1, L.pixels.data());   // header over the host copy
+        // the library writes straight into the caller's containers: keypoints sized to the handle's capacity and cut
+        // to the count afterwards, descriptors into a capacity-row matrix of which the first n rows are returned
+        int n = 0;
+        const int mono = impl_.extract_into(image.data, image.cols, image.rows, (ptrdiff_t)image.step, vLappingArea,
+                                            [&](int cap) { _keypoints.resize(cap); return reinterpret_cast<orbx_keypoint*>(_keypoints.data()); },
+                                            [&](int cap) { desc_.create(cap, 32, CV_8U); return desc_.data; }, &n);
+        _keypoints.resize(n);
+        if (n == 0) _descriptors.release();
+        else { _descriptors.create(n, 32, CV_8U); std::memcpy(_descriptors.getMat().data, desc_.data, (size_t)n * 32); }
+        // Frame::ComputeStereoMatches reads mvImagePyramid in the reference; with orbx_stereo_match it does not, so the
+        // eight level images are only brought back to the host on request
+        if (keepPyramid) {
+            impl_.fetch_pyramid();
+            mvImagePyramid.resize(impl_.mvImagePyramid.size());
+            for (size_t l = 0; l < impl_.mvImagePyramid.size(); ++l) {
+                orbx::Level& L = impl_.mvImagePyramid[l];
+                mvImagePyramid[l] = cv::Mat(L.height, L.width, CV_8UC1, L.pixels.data());   // header over the host copy
+            }
         }
         return mono;
     }
+    bool keepPyramid = false;
     int GetLevels() { return impl_.GetLevels(); }
     float GetScaleFactor() { return impl_.GetScaleFactor(); }
     std::vector<float> GetScaleFactors() { return impl_.GetScaleFactors(); }
@@ -191,6 +220,7 @@ public:
     orbx::Extractor& impl() { return impl_; }
 private:
     orbx::Extractor impl_;
+    cv::Mat desc_;     // capacity rows, reused from call to call
 };
 }  // namespace ORB_SLAM3
 #endif  // ORBX_WITH_OPENCV

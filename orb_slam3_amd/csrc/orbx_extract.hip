@@ -1731,6 +1731,37 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
     return ORBX_OK;
 }
 
+// Scale tables and per-level quotas: ORBextractor.cc:481-512 (scaleFactor is a double member).  Host arithmetic only.
+static void host_scale_tables(int nfeatures, float scale_factor, int nl, float* sf, float* inv_sf, float* sigma2, float* inv_sigma2,
+                              int* quota) {
+    const double scaleFactor = (double)scale_factor;
+    sf[0] = 1.f; sigma2[0] = 1.f;
+    for (int i = 1; i < nl; ++i) { sf[i] = (float)(sf[i - 1] * scaleFactor); sigma2[i] = sf[i] * sf[i]; }
+    for (int i = 0; i < nl; ++i) { inv_sf[i] = 1.0f / sf[i]; inv_sigma2[i] = 1.0f / sigma2[i]; }
+    const float factor = (float)(1.0f / scaleFactor);
+    float per = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
+    int sum = 0;
+    for (int l = 0; l < nl - 1; ++l) { quota[l] = round_half_even_f(per); sum += quota[l]; per *= factor; }
+    quota[nl - 1] = std::max(nfeatures - sum, 0);
+}
+
+extern "C" orbx_status orbx_scale_tables(int nfeatures, float scale_factor, int nlevels, float* scale, float* inv_scale,
+                                         float* sigma2, float* inv_sigma2, int* features_per_level) {
+    ORBX_REQUIRE(nlevels >= 1 && nlevels <= kOrbxMaxLevels, "nlevels must be in [1, %d]", kOrbxMaxLevels);
+    ORBX_REQUIRE(nfeatures >= 1 && scale_factor > 1.0f, "bad nfeatures / scale_factor");
+    float sf[kOrbxMaxLevels], isf[kOrbxMaxLevels], s2[kOrbxMaxLevels], is2[kOrbxMaxLevels];
+    int q[kOrbxMaxLevels];
+    host_scale_tables(nfeatures, scale_factor, nlevels, sf, isf, s2, is2, q);
+    for (int i = 0; i < nlevels; ++i) {
+        if (scale) scale[i] = sf[i];
+        if (inv_scale) inv_scale[i] = isf[i];
+        if (sigma2) sigma2[i] = s2[i];
+        if (inv_sigma2) inv_sigma2[i] = is2[i];
+        if (features_per_level) features_per_level[i] = q[i];
+    }
+    return ORBX_OK;
+}
+
 extern "C" orbx_status orbx_extractor_create(const orbx_params* p, orbx_extractor** out) {
     ORBX_REQUIRE(p && out, "null argument");
     ORBX_REQUIRE(p->nlevels >= 1 && p->nlevels <= kOrbxMaxLevels, "nlevels must be in [1, %d]", kOrbxMaxLevels);
@@ -1745,17 +1776,9 @@ extern "C" orbx_status orbx_extractor_create(const orbx_params* p, orbx_extracto
     if (p->device >= 0) ORBX_HIP_TRY(hipSetDevice(p->device));
     ORBX_HIP_TRY(hipGetDevice(&ex->device));
     const int nl = p->nlevels;
-    // scale tables and per-level quotas: ORBextractor.cc:481-512 (scaleFactor is a double member)
-    const double scaleFactor = (double)p->scale_factor;
     ex->sf.resize(nl); ex->inv_sf.resize(nl); ex->sigma2.resize(nl); ex->inv_sigma2.resize(nl); ex->quota.resize(nl);
-    ex->sf[0] = 1.f; ex->sigma2[0] = 1.f;
-    for (int i = 1; i < nl; ++i) { ex->sf[i] = (float)(ex->sf[i - 1] * scaleFactor); ex->sigma2[i] = ex->sf[i] * ex->sf[i]; }
-    for (int i = 0; i < nl; ++i) { ex->inv_sf[i] = 1.0f / ex->sf[i]; ex->inv_sigma2[i] = 1.0f / ex->sigma2[i]; }
-    const float factor = (float)(1.0f / scaleFactor);
-    float per = p->nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nl));
-    int sum = 0;
-    for (int l = 0; l < nl - 1; ++l) { ex->quota[l] = round_half_even_f(per); sum += ex->quota[l]; per *= factor; }
-    ex->quota[nl - 1] = std::max(p->nfeatures - sum, 0);
+    host_scale_tables(p->nfeatures, p->scale_factor, nl, ex->sf.data(), ex->inv_sf.data(), ex->sigma2.data(), ex->inv_sigma2.data(),
+                      ex->quota.data());
 
     orbx_status st = ORBX_OK;
     auto fail = [&](orbx_status s) { orbx_extractor_destroy(ex); return s; };

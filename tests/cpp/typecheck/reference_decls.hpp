@@ -24,6 +24,7 @@ struct Mat {
     template <class T> T* ptr(int row = 0);
     template <class T> const T* ptr(int row = 0) const;
     int type() const;
+    void create(int rows, int cols, int type);
     unsigned char* data;
     int rows, cols;
     size_t step;

@@ -131,3 +131,17 @@ def test_dist_library_exports_and_validates_without_device():
     assert b"communicator" in L.orbx_last_error()
     assert D.orbx_extract_pool_devices(None) == 0
     assert D.orbx_rccl_unique_id(None) == _lib.ORBX_ERR_INVALID
+
+
+def test_scale_tables_need_no_device(oracle):
+    """orbx_scale_tables is host arithmetic (ORBextractor.cc:481-512): equal to the oracle's tables, no handle, no GPU."""
+    from orb_slam3_amd import _lib
+    L = _lib.lib()
+    for nfeat, sf, nl in [(1000, 1.2, 8), (1200, 1.2, 8), (5000, 1.2, 8), (2000, 1.5, 5), (500, 1.1, 12)]:
+        a = [np.zeros(nl, np.float32) for _ in range(4)]
+        q = np.zeros(nl, np.int32)
+        assert L.orbx_scale_tables(nfeat, sf, nl, *[x.ctypes.data_as(C.c_void_p) for x in a], q.ctypes.data_as(C.c_void_p)) == 0
+        e = oracle.Extractor(nfeat, sf, nl, 20, 7)
+        assert np.array_equal(a[0], e.scale_factors) and np.array_equal(a[1], e.inv_scale_factors)
+        assert q.sum() == nfeat and (q >= 0).all()
+    assert L.orbx_scale_tables(1000, 1.0, 8, None, None, None, None, None) == _lib.ORBX_ERR_INVALID
