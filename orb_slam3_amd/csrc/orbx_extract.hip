@@ -162,20 +162,37 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__
             if (need0[r]) raw0[r] = resize_load(src + (long long)sy0[r] * S.pitch, base);
             if (need1[r]) raw1[r] = resize_load(src + (long long)sy1[r] * S.pitch, base);
         }
-        uint2 prev = make_uint2(0u, 0u);
+        // horizontal sums (p0 a0 + p1 a1) >> 4 of a source row are computed once: the lower row of one output row is
+        // the upper row of the next whenever the vertical taps say so
+        uint32_t prevT[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int r = 0; r < kResizeRows; ++r) {
             if (!live[r]) break;
-            const uint2 g0 = need0[r] ? resize_gather(raw0[r], sh, sel0, sel1) : prev;
-            const uint2 g1 = need1[r] ? resize_gather(raw1[r], sh, sel0, sel1) : g0;
-            prev = g1;
+            uint32_t T0[4], T1[4];
+            if (need0[r]) {
+                const uint2 g = resize_gather(raw0[r], sh, sel0, sel1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    T0[i] = (((g.x >> (8 * i)) & 255u) * (uint32_t)a0[i] + ((g.y >> (8 * i)) & 255u) * (uint32_t)a1[i]) >> 4;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) T0[i] = prevT[i];
+            }
+            if (need1[r]) {
+                const uint2 g = resize_gather(raw1[r], sh, sel0, sel1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    T1[i] = (((g.x >> (8 * i)) & 255u) * (uint32_t)a0[i] + ((g.y >> (8 * i)) & 255u) * (uint32_t)a1[i]) >> 4;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) T1[i] = T0[i];
+            }
             uint32_t packed = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int t0 = (int)((g0.x >> (8 * i)) & 255u) * a0[i] + (int)((g0.y >> (8 * i)) & 255u) * a1[i];
-                const int t1 = (int)((g1.x >> (8 * i)) & 255u) * a0[i] + (int)((g1.y >> (8 * i)) & 255u) * a1[i];
-                const int v = (((b0[r] * (t0 >> 4)) >> 16) + ((b1[r] * (t1 >> 4)) >> 16) + 2) >> 2;
-                packed |= (uint32_t)(v & 255) << (8 * i);
+                prevT[i] = T1[i];
+                const uint32_t v = ((((uint32_t)b0[r] * T0[i]) >> 16) + (((uint32_t)b1[r] * T1[i]) >> 16) + 2u) >> 2;
+                packed |= (v & 255u) << (8 * i);
             }
             *reinterpret_cast<uint32_t*>(dst + (long long)(yFirst + r) * D.pitch + x4) = packed;   // pitch padding absorbs the tail
         }
