@@ -69,6 +69,7 @@ struct OrbxFrameGeo {
     int maxNodeCap;
     int tileP, tileR;        // LDS tile of the FAST kernel: pitch (bytes) and rows
     int fastLds;             // its dynamic LDS size in bytes
+    int fastQueueOff;        // byte offset of its survivor queue in that memory
     OrbxLevelGeo lv[kOrbxMaxLevels];
 };
 

@@ -309,6 +309,14 @@ __device__ __forceinline__ int fast_strength_lds(const uint8_t* t, int P, int x,
     return st;
 }
 
+// Rows per band when `lanes` lanes share a cell of ncol dword columns and ih testable rows, one lane per
+// (band, column).  Host and kernel use the same arithmetic.
+__host__ __device__ __forceinline__ int fast_band_rows(int ncol, int ih, int lanes) {
+    const int q = lanes / ncol;
+    const int bands = q < 1 ? 1 : (q < ih ? q : ih);
+    return (ih + bands - 1) / bands;
+}
+
 __device__ __forceinline__ int score_at(int strength, int th) { return strength > th ? strength - 1 : 0; }
 
 // cv::Rect2i::contains(Point2i(pt)): the float point converts with round-half-even.
@@ -322,6 +330,12 @@ __device__ __forceinline__ bool in_any_rect(float X, float Y, const orbx_rect* r
 }
 
 constexpr int kFastThreads = 128;
+#ifndef ORBX_QR_SHIFT
+#define ORBX_QR_SHIFT 1
+#endif
+// The quick reject of k_fast compares pixels without their kQrShift low bits (see there).
+constexpr int kQrShift = ORBX_QR_SHIFT;
+constexpr uint32_t kQrMask = (0xFFu >> kQrShift) * 0x01010101u;
 
 // Diagnostic build only (-DORBX_FAST_STAMPS, tools/prof_fast_phases.py): wave 0 of every workgroup adds the shader
 // cycles it spent between the phase boundaries of k_fast to a device array; the product library contains none of it.
@@ -413,16 +427,19 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
                                                        const orbx_rect* __restrict__ rects, int nrects,
                                                        OrbxErr* __restrict__ err) {
     // Dynamic LDS: image tile [R][P] (stored from the 4-byte aligned column at or left of the
-    // cell so that rows are fetched with dword loads), strength tile [R][P], and the queue of
+    // cell so that rows are fetched with dword loads), strength tile [R][P], the image tile again with every
+    // pixel shifted right by kQrShift bits (what the quick reject compares), and the queue of
     // pixels that survive the quick reject (one ushort per testable pixel), later compacted in
-    // place to those that are corners.  After the strengths are known the image tile is reused for
+    // place to those that are corners.  The queue starts where the host put it: on top of the coarse tile when
+    // the quick reject reads all of that tile before it queues anything, behind it otherwise.  After the strengths are known the image tile is reused for
     // the list of corners that survive the non-maximum suppression.
     extern __shared__ __align__(16) unsigned char fast_smem[];
     __shared__ int s_nQueue, s_nIni, s_nMin, s_nKeep;
     const int P = kP ? kP : geo->tileP, R = geo->tileR;
     uint8_t* tile = fast_smem;
     uint8_t* strength = tile + P * R;
-    unsigned short* s_queue = reinterpret_cast<unsigned short*>(strength + P * R);
+    uint8_t* coarse = strength + P * R;
+    unsigned short* s_queue = reinterpret_cast<unsigned short*>(fast_smem + geo->fastQueueOff);
 
     // neighbouring cells overlap by 6 pixels: keep them on one XCD (see xcd_remap)
     const int nCellsAll = gridDim.x;
@@ -456,14 +473,17 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
             if (row < rowsPerPass) {
                 const uint8_t* src = img + (long long)(y0 + row) * G.pitch + xa + 16 * xc;
                 uint8_t* dstT = tile + row * P + 16 * xc;
-                uint8_t* dstS = strength + row * P + 16 * xc;
+                const int planeBytes = P * R;
                 const long long srcStep = (long long)rowsPerPass * G.pitch;
                 const int dstStep = rowsPerPass * P;
                 for (int y = row; y < th; y += rowsPerPass) {
                     const Chunk16 v = *reinterpret_cast<const Chunk16*>(src);
                     *reinterpret_cast<uint4*>(dstT) = make_uint4(v.a, v.b, v.c, v.d);
-                    *reinterpret_cast<uint4*>(dstS) = make_uint4(0u, 0u, 0u, 0u);
-                    src += srcStep; dstT += dstStep; dstS += dstStep;
+                    *reinterpret_cast<uint4*>(dstT + planeBytes) = make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(dstT + 2 * planeBytes) =
+                        make_uint4((v.a >> kQrShift) & kQrMask, (v.b >> kQrShift) & kQrMask, (v.c >> kQrShift) & kQrMask,
+                                   (v.d >> kQrShift) & kQrMask);
+                    src += srcStep; dstT += dstStep;
                 }
             }
         } else {
@@ -474,13 +494,15 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
             if (row < rowsPerPass && xd < rowDwords) {
                 const uint8_t* src = img + (long long)(y0 + row) * G.pitch + xa + 4 * xd;
                 uint8_t* dstT = tile + row * P + 4 * xd;
-                uint8_t* dstS = strength + row * P + 4 * xd;
+                const int planeBytes = P * R;
                 const long long srcStep = (long long)rowsPerPass * G.pitch;
                 const int dstStep = rowsPerPass * P;
                 for (int y = row; y < th; y += rowsPerPass) {
-                    *reinterpret_cast<uint32_t*>(dstT) = *reinterpret_cast<const uint32_t*>(src);
-                    *reinterpret_cast<uint32_t*>(dstS) = 0u;
-                    src += srcStep; dstT += dstStep; dstS += dstStep;
+                    const uint32_t v = *reinterpret_cast<const uint32_t*>(src);
+                    *reinterpret_cast<uint32_t*>(dstT) = v;
+                    *reinterpret_cast<uint32_t*>(dstT + planeBytes) = 0u;
+                    *reinterpret_cast<uint32_t*>(dstT + 2 * planeBytes) = (v >> kQrShift) & kQrMask;
+                    src += srcStep; dstT += dstStep;
                 }
             }
         }
@@ -499,30 +521,34 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
         // {0,8} (3 rows below / above), {4,12} (3 columns right / left) and the diagonal pairs {2,10}, {6,14}.
         // (Two pairs let about a quarter of a textured image through, four pairs about a third of that, and
         // every survivor costs a full arc evaluation in (B).)
-        // Four pixels (one tile dword) per lane and step, compared byte-wise with v_lerp_u8:
-        //   lerp(a, ~b, c) = (a - b + 255 + c) >> 1 per byte, so with c chosen to make t + 256 + c even
-        //   "a - b > t"  <=>  lerp(a, ~b, c) >= K := (t + 256 + c) / 2  <=>  bit 7 of lerp(lerp(a, ~b, c), ~K, 1).
-        // Three lerps per neighbour: the half-difference, its test against K (brighter) and against Z (darker).
+        // The test runs on the coarse tile, n' = n >> kQrShift per byte: n - c >= t implies n' - c' >= t >> kQrShift
+        // (floor is superadditive), so comparing the coarse values against tq = t >> kQrShift loses no corner and
+        // lets through a few pixels whose difference is just below the threshold; (B) evaluates survivors exactly.
+        // Coarse bytes have spare high bits, which makes a byte-wise comparison ONE 32-bit add or subtract on four
+        // pixels with the verdict in bit 7 of each byte and no carry between bytes:
+        //   brighter:  n' - c' >= tq  <=>  bit 7 of n' + Cb,  Cb = max(128 - tq - c', 0)
+        //   darker:    c' - n' >= tq  <=>  bit 7 of Cd - n',  Cd = max(c' + 128 - tq, 127)
+        // (plain 32-bit add / subtract / logic with register or literal operands issue at twice the rate of the byte
+        // instructions; the constants therefore live in vector registers).  Cb and Cd are per centre pixel; with
+        // kQrShift = 2 no clamp is needed because 6-bit values cannot leave the byte.
         // The testable pixels are cut into horizontal bands; a lane walks down one dword column of one
         // band with the 7 rows (y-3 .. y+3) of that column and of its two neighbours in registers, so each
-        // further 4 pixels cost three LDS dword reads.  One wave does the whole cell (fewer instructions than two waves with
-        // shorter bands); survivors are collected in a per-lane nibble mask and queued at the end.
-        if (tid < 64) {
+        // further 4 pixels cost three LDS dword reads.  Survivors are collected in a per-lane bit mask and queued at the end.
+        // One wave does the whole cell when its bands fit one 8-row pass (fewer instructions than two waves with
+        // shorter bands); cells whose bands would be taller are shared by both waves.
+        const int dFirst = (ox + 3) >> 2, dLast = (ox + 3 + iw - 1) >> 2;     // tile dword columns with testable pixels
+        const int ncol = dLast - dFirst + 1;
+        const bool bothWaves = fast_band_rows(ncol, ih, 64) > 8;
+        const int qrLanes = bothWaves ? 128 : 64;
+        if (tid < qrLanes) {
             const int t1 = lowTh + 1;                                  // a - b >= t1
-            const uint32_t cRound = ((t1 + 255) & 1) ? 0x01010101u : 0u;
-            // K = 256 (threshold 255: nothing can pass) is clamped; the few extra survivors are rejected by (B)
-            const uint32_t K = min((uint32_t)((t1 + 255 + (cRound & 1u)) >> 1), 255u);
-            const uint32_t nK = ~(K * 0x01010101u);
-            // The same half-difference h = (neighbour - centre + 255 + c) >> 1 answers the dark side: centre -
-            // neighbour >= t1 means neighbour - centre + 255 + c <= Z := 255 + c - t1, which implies h <= Z >> 1,
-            // i.e. NOT h >= (Z >> 1) + 1.  (The converse fails for one value of the difference: a few more
-            // survivors, which (B) rejects.)
-            const int Z = 255 + (int)(cRound & 1u) - t1;
-            const uint32_t nZ = ~((uint32_t)((Z >> 1) + 1) * 0x01010101u);
-            const int dFirst = (ox + 3) >> 2, dLast = (ox + 3 + iw - 1) >> 2;     // tile dword columns with testable pixels
-            const int ncol = dLast - dFirst + 1;
-            const int bands = max(1, min(64 / ncol, ih));
-            const int bandRows = (ih + bands - 1) / bands;                      // <= 8 nibbles fit the 32-bit mask when <= 8
+            const int tq = min(t1 >> kQrShift, (int)(0xFFu >> kQrShift));
+            const bool passAll = tq < 1;                               // thresholds below the coarse step: everything survives
+            uint32_t KB0 = (uint32_t)(128 - max(tq, 1)) * 0x01010101u;     // 128 - tq per byte
+            uint32_t KB0H = KB0 | 0x80808080u;
+            asm volatile("" : "+v"(KB0), "+v"(KB0H));                  // vector registers: a scalar operand halves the issue rate
+            const int bands = max(1, min(qrLanes / ncol, ih));
+            const int bandRows = (ih + bands - 1) / bands;
             const int band = tid / ncol, d = dFirst + (tid - band * ncol);
             const bool laneOn = band < bands;
             const int yBeg = 3 + band * bandRows;
@@ -537,7 +563,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
             for (int chunk = 0; chunk < bandRows; chunk += 8) {
                 const int yc = yBeg + chunk;
                 const int rows = min(8, bandRows - chunk);             // uniform
-                const uint32_t* c = reinterpret_cast<const uint32_t*>(tile + (laneOn ? yc : 3) * P) + (laneOn ? d : 1);
+                const uint32_t* c = reinterpret_cast<const uint32_t*>(coarse + (laneOn ? yc : 3) * P) + (laneOn ? d : 1);
                 const int PD = P >> 2;                                 // row pitch in dwords
                 // the dword columns left and right of the lane's own (clamped to the row: a clamped column is only
                 // ever the source of bytes that no testable pixel of this lane uses)
@@ -548,31 +574,38 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
                          L5 = c[2 * PD + dl], L6 = c[3 * PD + dl];
                 uint32_t R0 = c[-3 * PD + dr], R1 = c[-2 * PD + dr], R2 = c[-PD + dr], R3 = c[dr], R4 = c[PD + dr],
                          R5 = c[2 * PD + dr], R6 = c[3 * PD + dr];
-                uint32_t mask = 0;   // row yc + i of the chunk ends up in nibble rows - 1 - i
+                // Row yc + i of the chunk sets bit 8 - rows + i of byte k for pixel k of the dword: the mask moves down
+                // one bit per row and the new verdicts enter at bit 7 of each byte (at most 8 rows, so no bit leaves
+                // its byte).
+                uint32_t mask = 0;
                 // circle pixels used: 0 / 8 (0, +-3), 4 / 12 (+-3, 0), 2 / 10 (+2, +2) / (-2, -2), 6 / 14 (+2, -2) / (-2, +2)
-#define ORBX_H(px) __builtin_amdgcn_lerp(px, nC, cRound)
-#define ORBX_B(h) __builtin_amdgcn_lerp(h, nK, 0x01010101u)
-#define ORBX_E(h) __builtin_amdgcn_lerp(h, nZ, 0x01010101u)
 #define ORBX_FAST_ROW4(i0, i1, i2, i3, i4, i5, i6, r)                                                       \
                 if ((r) < rows) {                                                                           \
-                    const uint32_t nC = ~C##i3;                                                             \
-                    /* per byte (neighbour - centre + 255 + c) >> 1: one value serves both polarities */    \
-                    const uint32_t hU = ORBX_H(C##i0), hD = ORBX_H(C##i6);                                  \
-                    const uint32_t hL = ORBX_H(__builtin_amdgcn_alignbyte(C##i3, L##i3, 1));   /* x - 3 */  \
-                    const uint32_t hR = ORBX_H(__builtin_amdgcn_alignbyte(R##i3, C##i3, 3));   /* x + 3 */  \
-                    const uint32_t hA = ORBX_H(__builtin_amdgcn_alignbyte(R##i5, C##i5, 2));   /* (+2, +2) */ \
-                    const uint32_t hB = ORBX_H(__builtin_amdgcn_alignbyte(C##i1, L##i1, 2));   /* (-2, -2) */ \
-                    const uint32_t hP = ORBX_H(__builtin_amdgcn_alignbyte(R##i1, C##i1, 2));   /* (+2, -2) */ \
-                    const uint32_t hQ = ORBX_H(__builtin_amdgcn_alignbyte(C##i5, L##i5, 2));   /* (-2, +2) */ \
-                    /* bit 7 set: neighbour brighter than the centre by more than the threshold */          \
-                    const uint32_t br = (ORBX_B(hU) | ORBX_B(hD)) & (ORBX_B(hL) | ORBX_B(hR)) &             \
-                                        (ORBX_B(hA) | ORBX_B(hB)) & (ORBX_B(hP) | ORBX_B(hQ));              \
-                    /* bit 7 clear: neighbour darker than the centre by more than the threshold (or by exactly it) */ \
-                    const uint32_t nd = (ORBX_E(hU) & ORBX_E(hD)) | (ORBX_E(hL) & ORBX_E(hR)) |             \
-                                        (ORBX_E(hA) & ORBX_E(hB)) | (ORBX_E(hP) & ORBX_E(hQ));              \
-                    const uint32_t F = (br | ~nd) & valid;                                                  \
-                    /* the four flag bits (7, 15, 23, 31) gathered into one nibble */                       \
-                    mask = (mask << 4) | (((F >> 7) * 0x00204081u) >> 21 & 15u);                            \
+                    uint32_t Cb, Cd;                                                                        \
+                    if (kQrShift >= 2) {                                                                    \
+                        Cb = KB0 - C##i3;                                                                   \
+                        Cd = C##i3 + KB0;                                                                   \
+                    } else {                                                                                \
+                        const uint32_t V = KB0H - C##i3;              /* 256 - tq - c': bit 7 = "not negative" */ \
+                        const uint32_t mB = V & 0x80808080u;                                                \
+                        Cb = V & (mB - (mB >> 7));                                                          \
+                        const uint32_t W = C##i3 + KB0;                                                     \
+                        const uint32_t mD = W & 0x80808080u;                                                \
+                        Cd = W | ((mD - (mD >> 7)) ^ 0x7F7F7F7Fu);                                          \
+                    }                                                                                       \
+                    const uint32_t nU = C##i0, nD = C##i6;                                                  \
+                    const uint32_t nL = __builtin_amdgcn_alignbyte(C##i3, L##i3, 1);   /* x - 3 */          \
+                    const uint32_t nR = __builtin_amdgcn_alignbyte(R##i3, C##i3, 3);   /* x + 3 */          \
+                    const uint32_t nA = __builtin_amdgcn_alignbyte(R##i5, C##i5, 2);   /* (+2, +2) */       \
+                    const uint32_t nB = __builtin_amdgcn_alignbyte(C##i1, L##i1, 2);   /* (-2, -2) */       \
+                    const uint32_t nP = __builtin_amdgcn_alignbyte(R##i1, C##i1, 2);   /* (+2, -2) */       \
+                    const uint32_t nQ = __builtin_amdgcn_alignbyte(C##i5, L##i5, 2);   /* (-2, +2) */       \
+                    /* bit 7 of each byte: brighter / darker than the centre by the threshold */            \
+                    const uint32_t br = ((nU + Cb) | (nD + Cb)) & ((nL + Cb) | (nR + Cb)) &                 \
+                                        ((nA + Cb) | (nB + Cb)) & ((nP + Cb) | (nQ + Cb));                  \
+                    const uint32_t dk = ((Cd - nU) | (Cd - nD)) & ((Cd - nL) | (Cd - nR)) &                 \
+                                        ((Cd - nA) | (Cd - nB)) & ((Cd - nP) | (Cd - nQ));                  \
+                    mask = (mask >> 1) | ((br | dk) & valid);                                               \
                     c += PD;                                                                                \
                     C##i0 = c[3 * PD]; L##i0 = c[3 * PD + dl]; R##i0 = c[3 * PD + dr];                      \
                 }
@@ -585,21 +618,25 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
                     ORBX_FAST_ROW4(5, 6, 0, 1, 2, 3, 4, r + 5)
                     ORBX_FAST_ROW4(6, 0, 1, 2, 3, 4, 5, r + 6)
                 }
-#undef ORBX_H
-#undef ORBX_B
-#undef ORBX_E
 #undef ORBX_FAST_ROW4
-                // keep the rows inside the lane's band / the cell: the first `valid` rows of the chunk
+                // keep the rows inside the lane's band / the cell: the first `nvalid` rows of the chunk, i.e. the
+                // bits below 8 - rows + nvalid of every byte
                 const int nvalid = min(yEnd - yc, rows);
-                uint32_t m = (nvalid <= 0) ? 0u : (mask >> (4 * (rows - nvalid)));
+                const int rowBit0 = 8 - rows;
+                uint32_t m = 0;
+                if (nvalid > 0) {
+                    const uint32_t keepBits = (((1u << (rowBit0 + nvalid)) - 1u) & 0xFFu) * 0x01010101u;
+                    m = passAll ? ((((1u << nvalid) - 1u) << rowBit0) * (((valid >> 7) & 0x01010101u))) : (mask & keepBits);
+                }
                 const int cnt = __popc(m);
+                if (bothWaves) __syncthreads();     // the queue may lie on the coarse tile the other wave still reads
                 if (cnt) {
                     int base = atomicAdd(&s_nQueue, cnt);
                     while (m) {
-                        const int i = __ffs(m) - 1;       // nibble i >> 2 = row yc + nvalid - 1 - (i >> 2), bit i & 3 = byte of the dword
+                        const int i = __ffs(m) - 1;       // byte i >> 3 = pixel of the dword, bit i & 7 = rowBit0 + row of the chunk
                         m &= m - 1;
-                        const int x = 4 * d + (i & 3) - ox;
-                        s_queue[base++] = (unsigned short)(x | ((yc + nvalid - 1 - (i >> 2)) << 7));
+                        const int x = 4 * d + (i >> 3) - ox;
+                        s_queue[base++] = (unsigned short)(x | ((yc + (i & 7) - rowBit0) << 7));
                     }
                 }
             }
@@ -1676,7 +1713,21 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
         g.tileP = (mw + 3 + 3) & ~3;     // widest cell image + alignment shift, multiple of 4
         if (g.tileP <= 48) g.tileP = 48; // the common 35..39-px cells share the kernel instance with a constant pitch
         g.tileR = mh;
-        g.fastLds = 2 * g.tileP * g.tileR + 2 * ((mw - 6) * (mh - 6) + 4);
+        // k_fast's survivor queue shares the memory of the coarse tile when every lane of the quick reject is done
+        // with that tile before the first survivor is queued, i.e. when no band of any level has more than the 8
+        // rows one pass covers (the same arithmetic as in the kernel, for the widest / tallest cell and every
+        // alignment shift).
+        int maxBandRows = 0;
+        for (int l = 0; l < P.nlevels; ++l)
+            for (int ox = 0; ox < 4; ++ox) {
+                const int iw = g.lv[l].wCell, ih = g.lv[l].hCell;
+                const int ncol = ((ox + 3 + iw - 1) >> 2) - ((ox + 3) >> 2) + 1;
+                const int rows1 = fast_band_rows(ncol, ih, 64);
+                maxBandRows = std::max(maxBandRows, rows1 > 8 ? fast_band_rows(ncol, ih, 128) : rows1);
+            }
+        const int plane = g.tileP * g.tileR, queueBytes = 2 * ((mw - 6) * (mh - 6) + 4);
+        if (maxBandRows <= 8) { g.fastQueueOff = 2 * plane; g.fastLds = 2 * plane + std::max(plane, queueBytes); }
+        else { g.fastQueueOff = 3 * plane; g.fastLds = 3 * plane + queueBytes; }
     }
 
     {
