@@ -81,6 +81,28 @@ struct OrbxCand {
 };
 
 // Keypoint kept by the quadtree (level coordinates, +16 applied).
+// Per-cell constants of k_fast, built on the host (one scalar load of 32 bytes per workgroup).
+struct alignas(32) OrbxFastCell {
+    int xy;                  // x0 | y0 << 16: top-left of the cell image in level coordinates
+    int dims;                // width | height << 8 | level << 16
+    int index;               // index among the level's processed cells (row-major)
+    int apps;                // cells from this one to the level's last
+    int tileOff;             // byte offset, inside a frame's pyramid slab, of the tile's first (4-byte aligned) column
+    int pitch;               // row pitch of the level
+    int pad0, pad1;
+};
+
+// What k_describe needs to know about one kept keypoint, written by k_layout for the j-th keypoint of a frame in
+// (level, list) order: one 32-byte scalar load replaces the walk level table -> level geometry -> keypoint record.
+struct alignas(32) OrbxDescWork {
+    int imgOff;              // byte offset of the level image inside the frame's pyramid slab
+    int pitch;               // of that level
+    int wh;                  // its width | height << 16
+    int cxy;                 // rounded level coordinates of the keypoint, cx | cy << 16
+    int slotLevel;           // row in the frame's output arrays | level << 24
+    float x, y, response;    // the keypoint record (level coordinates)
+};
+
 struct OrbxLevelKp {
     float x, y;
     float response;

@@ -84,6 +84,7 @@ struct OrbxErr {
 // ======================================================================================
 constexpr int kResizeRows = 4;   // output rows per lane: taps are fetched once, source rows are reused
 
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
 // the three aligned dwords that hold a lane's 8-byte source window of one row
 struct ResizeRaw { uint32_t d0, d1, d2; };
 __device__ __forceinline__ ResizeRaw resize_load(const uint8_t* __restrict__ row, int base) {
@@ -92,10 +93,16 @@ __device__ __forceinline__ ResizeRaw resize_load(const uint8_t* __restrict__ row
     r.d0 = p[0]; r.d1 = p[1]; r.d2 = p[2];
     return r;
 }
-// the four left (.x) and right (.y) neighbours of the lane's outputs, cut out of the window
-__device__ __forceinline__ uint2 resize_gather(const ResizeRaw r, int sh, uint32_t sel0, uint32_t sel1) {
+// Horizontal pass of one source row for the lane's four outputs: (p0 a0 + p1 a1) >> 4 each.  One v_perm_b32 per
+// output puts its left and right neighbour into the two halves of a dword ([p0, 0, p1, 0], selector byte 0x0C = zero),
+// and v_dot2_u32_u16 against the coefficient pair (a0 | a1 << 16, as the tap table stores it) is the whole sum.
+__device__ __forceinline__ void resize_hsum(const ResizeRaw r, int sh, const uint32_t (&sel)[4], const uint32_t (&co)[4],
+                                            uint32_t (&T)[4]) {
     const uint32_t w0 = __builtin_amdgcn_alignbyte(r.d1, r.d0, sh), w1 = __builtin_amdgcn_alignbyte(r.d2, r.d1, sh);
-    return make_uint2(__builtin_amdgcn_perm(w1, w0, sel0), __builtin_amdgcn_perm(w1, w0, sel1));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        T[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2v, __builtin_amdgcn_perm(w1, w0, sel[i])),
+                                      __builtin_bit_cast(us2v, co[i]), 0u, false) >> 4;
 }
 
 __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__ geo, int level,
@@ -127,12 +134,10 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__
     // byte positions inside the 8-byte window that starts at source column so[0]
     const int last = min(o.w + 1, S.w - 1);
     const bool window = last - o.x < 8;
-    uint32_t sel0 = 0, sel1 = 0;
+    uint32_t sel[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        sel0 |= (uint32_t)((so[i] - o.x) & 7) << (8 * i);
-        sel1 |= (uint32_t)((min(so[i] + 1, S.w - 1) - o.x) & 7) << (8 * i);
-    }
+    for (int i = 0; i < 4; ++i)
+        sel[i] = 0x0C000C00u | (uint32_t)((so[i] - o.x) & 7) | ((uint32_t)((min(so[i] + 1, S.w - 1) - o.x) & 7) << 16);
     const int base = o.x & ~3, sh = o.x & 3;
 
     // Vertical taps of the lane's rows (wave-uniform), then every source row the rows need is requested before
@@ -170,29 +175,25 @@ __global__ __launch_bounds__(256) void k_resize(const OrbxFrameGeo* __restrict__
             if (!live[r]) break;
             uint32_t T0[4], T1[4];
             if (need0[r]) {
-                const uint2 g = resize_gather(raw0[r], sh, sel0, sel1);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    T0[i] = (((g.x >> (8 * i)) & 255u) * (uint32_t)a0[i] + ((g.y >> (8 * i)) & 255u) * (uint32_t)a1[i]) >> 4;
+                resize_hsum(raw0[r], sh, sel, co, T0);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) T0[i] = prevT[i];
             }
             if (need1[r]) {
-                const uint2 g = resize_gather(raw1[r], sh, sel0, sel1);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    T1[i] = (((g.x >> (8 * i)) & 255u) * (uint32_t)a0[i] + ((g.y >> (8 * i)) & 255u) * (uint32_t)a1[i]) >> 4;
+                resize_hsum(raw1[r], sh, sel, co, T1);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) T1[i] = T0[i];
             }
+            // (b T) >> 16 as the high half of (b << 16) T
+            const uint32_t b0s = (uint32_t)b0[r] << 16, b1s = (uint32_t)b1[r] << 16;
             uint32_t packed = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 prevT[i] = T1[i];
-                const uint32_t v = ((((uint32_t)b0[r] * T0[i]) >> 16) + (((uint32_t)b1[r] * T1[i]) >> 16) + 2u) >> 2;
-                packed |= (v & 255u) << (8 * i);
+                const uint32_t v = (__umulhi(b0s, T0[i]) + __umulhi(b1s, T1[i]) + 2u) >> 2;     // <= 255
+                packed |= v << (8 * i);
             }
             *reinterpret_cast<uint32_t*>(dst + (long long)(yFirst + r) * D.pitch + x4) = packed;   // pitch padding absorbs the tail
         }
@@ -412,7 +413,7 @@ extern "C" int orbx_debug_desc_stamps(unsigned long long* out8, int reset) {
 #endif
 #ifdef ORBX_DESC_STOP
 // (the value keeps what the phases so far have produced alive: without a consumer the compiler drops them)
-#define ORBX_DESC_PHASE_END(n, value) do { if (ORBX_DESC_STOP == (n)) { if (active) outDesc[((long long)frame * capacity + kp.slot) * 32 + (lane & 31)] = (uint8_t)(value); return; } } while (0)
+#define ORBX_DESC_PHASE_END(n, value) do { if (ORBX_DESC_STOP == (n)) { if (active) outDesc[((long long)frame * capacity + G.slot) * 32 + (lane & 31)] = (uint8_t)(value); return; } } while (0)
 #else
 #define ORBX_DESC_PHASE_END(n, value) do {} while (0)
 #endif
@@ -420,12 +421,14 @@ extern "C" int orbx_debug_desc_stamps(unsigned long long* out8, int reset) {
 // kP = LDS tile pitch known at compile time (row steps and the 3-row look-ahead become
 // immediate offsets), or 0 to take it from the geometry.
 template <int kP>
-__global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __restrict__ geo, const int4* __restrict__ cells,
+__global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __restrict__ geo,
+                                                       const OrbxFastCell* __restrict__ cells,
                                                        const uint8_t* __restrict__ pyr,
                                                        long long frameStride, OrbxCand* __restrict__ cands,
                                                        int* __restrict__ candCount, int iniTh, int minTh,
                                                        const orbx_rect* __restrict__ rects, int nrects,
-                                                       OrbxErr* __restrict__ err) {
+                                                       OrbxErr* __restrict__ err, int tileP, int tileR, int queueOff,
+                                                       int nl, unsigned int cellMagic) {
     // Dynamic LDS: image tile [R][P] (stored from the 4-byte aligned column at or left of the
     // cell so that rows are fetched with dword loads), strength tile [R][P], the image tile again with every
     // pixel shifted right by kQrShift bits (what the quick reject compares), and the queue of
@@ -435,32 +438,30 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     // the list of corners that survive the non-maximum suppression.
     extern __shared__ __align__(16) unsigned char fast_smem[];
     __shared__ int s_nQueue, s_nIni, s_nMin, s_nKeep;
-    const int P = kP ? kP : geo->tileP, R = geo->tileR;
+    const int P = kP ? kP : tileP, R = tileR;   // tile geometry and queue offset: OrbxFrameGeo::tileP / tileR / fastQueueOff
     uint8_t* tile = fast_smem;
     uint8_t* strength = tile + P * R;
     uint8_t* coarse = strength + P * R;
-    unsigned short* s_queue = reinterpret_cast<unsigned short*>(fast_smem + geo->fastQueueOff);
+    unsigned short* s_queue = reinterpret_cast<unsigned short*>(fast_smem + queueOff);
 
     // neighbouring cells overlap by 6 pixels: keep them on one XCD (see xcd_remap)
     const int nCellsAll = gridDim.x;
     const int logical = xcd_remap(blockIdx.y * nCellsAll + blockIdx.x, nCellsAll * gridDim.y);
-    const int frame = logical / nCellsAll;
+    // logical / nCellsAll through the host's reciprocal (exact for this grid, see enqueue_batch)
+    const int frame = cellMagic ? (int)__umulhi((unsigned int)logical, cellMagic) : logical / nCellsAll;
     const int cellAll = logical - frame * nCellsAll;
-    // per-cell constants precomputed on the host: {x0 | y0 << 16, tw | th << 8 | level << 16,
-    // index among the level's processed cells (row-major), cells from this one to the level's last}
-    const int4 CI = cells[cellAll];
-    const int x0 = CI.x & 0xFFFF, y0 = CI.x >> 16;
-    const int tw = CI.y & 255, th = (CI.y >> 8) & 255, level = CI.y >> 16;
-    const int cell = CI.z;
-    const int nl = geo->nlevels;
-    const OrbxLevelGeo& G = geo->lv[level];
+    const OrbxFastCell CI = cells[cellAll];
+    const int x0 = CI.xy & 0xFFFF, y0 = CI.xy >> 16;
+    const int tw = CI.dims & 255, th = (CI.dims >> 8) & 255, level = CI.dims >> 16;
+    const int cell = CI.index;
+    const int levelPitch = CI.pitch;
     const int tid = threadIdx.x;
     const int xa = x0 & ~3, ox = x0 - xa;
     const int rowDwords = (x0 + tw - xa + 3) >> 2;      // <= P / 4
 
     ORBX_STAMP_BEGIN();
     if (tid == 0) { s_nQueue = 0; s_nIni = 0; s_nMin = 0; s_nKeep = 0; }
-    const uint8_t* img = pyr + (long long)frame * frameStride + G.off;
+    const uint8_t* tileSrc = pyr + (long long)frame * frameStride + CI.tileOff;   // row y0, column xa of the level
     {
         // lane -> (row, 16-byte chunk of the row): the tile pitch is a multiple of 16 when it is the compile-time
         // one, and a multi-dword global load only needs dword alignment.  Chunks past the cell's columns are
@@ -471,10 +472,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
             const int row = tid / RC, xc = tid - row * RC;
             struct __attribute__((packed, aligned(4))) Chunk16 { uint32_t a, b, c, d; };
             if (row < rowsPerPass) {
-                const uint8_t* src = img + (long long)(y0 + row) * G.pitch + xa + 16 * xc;
+                const uint8_t* src = tileSrc + (long long)row * levelPitch + 16 * xc;
                 uint8_t* dstT = tile + row * P + 16 * xc;
                 const int planeBytes = P * R;
-                const long long srcStep = (long long)rowsPerPass * G.pitch;
+                const long long srcStep = (long long)rowsPerPass * levelPitch;
                 const int dstStep = rowsPerPass * P;
                 for (int y = row; y < th; y += rowsPerPass) {
                     const Chunk16 v = *reinterpret_cast<const Chunk16*>(src);
@@ -492,10 +493,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
             const int rowsPerPass = kFastThreads / RD;
             const int row = tid / RD, xd = tid - row * RD;
             if (row < rowsPerPass && xd < rowDwords) {
-                const uint8_t* src = img + (long long)(y0 + row) * G.pitch + xa + 4 * xd;
+                const uint8_t* src = tileSrc + (long long)row * levelPitch + 4 * xd;
                 uint8_t* dstT = tile + row * P + 4 * xd;
                 const int planeBytes = P * R;
-                const long long srcStep = (long long)rowsPerPass * G.pitch;
+                const long long srcStep = (long long)rowsPerPass * levelPitch;
                 const int dstStep = rowsPerPass * P;
                 for (int y = row; y < th; y += rowsPerPass) {
                     const uint32_t v = *reinterpret_cast<const uint32_t*>(src);
@@ -727,7 +728,8 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
 
     // Round trip: every corner found in the c-th processed cell is scaled to level 0 and
     // back once for each cell processed from its own to the last one of the level.
-    const int apps = CI.w;
+    const int apps = CI.apps;
+    const OrbxLevelGeo& G = geo->lv[level];
     const float s = G.scale, inv = G.invScale;
     const float border = (float)kOrbxMinBorder;
     OrbxCand* out = cands + (long long)frame * geo->candTotal + G.candOff;
@@ -1123,6 +1125,7 @@ __global__ __launch_bounds__(kLayThreads) void k_layout(const OrbxFrameGeo* __re
                                                         OrbxLevelKp* __restrict__ levelKps,
                                                         const int* __restrict__ kpCount, int lap0, int lap1,
                                                         int capacity, int* __restrict__ counts,
+                                                        OrbxDescWork* __restrict__ work,
                                                         OrbxErr* __restrict__ err) {
     __shared__ int s_wave[kLayThreads / 64];
     __shared__ int s_running;
@@ -1143,6 +1146,8 @@ __global__ __launch_bounds__(kLayThreads) void k_layout(const OrbxFrameGeo* __re
     for (int b = 0; b < total; b += kLayThreads) {
         const int j = b + tid;
         int mono = 0, l = 0, i = 0;
+        OrbxLevelKp rec;
+        rec.x = 0.f; rec.y = 0.f; rec.response = 0.f; rec.slot = -1;
         if (j < total) {
 #pragma unroll
             for (int q = 1; q < kOrbxMaxLevels; ++q) l += (j >= first[q]) ? 1 : 0;
@@ -1150,7 +1155,8 @@ __global__ __launch_bounds__(kLayThreads) void k_layout(const OrbxFrameGeo* __re
 #pragma unroll
             for (int q = 1; q < kOrbxMaxLevels; ++q) i = (l == q) ? j - first[q] : i;
             const OrbxLevelGeo& G = geo->lv[l];
-            float x = K[G.kpOff + i].x;
+            rec = K[G.kpOff + i];
+            float x = rec.x;
             if (l != 0) x = __fmul_rn(x, G.scale);
             mono = (x >= (float)lap0 && x <= (float)lap1) ? 0 : 1;
         }
@@ -1166,7 +1172,16 @@ __global__ __launch_bounds__(kLayThreads) void k_layout(const OrbxFrameGeo* __re
         if (j < total && !overflow) {
             const int monoBefore = running + wbase + before;
             const int stereoBefore = j - monoBefore;      // j keypoints precede this one in (level, list) order
-            K[geo->lv[l].kpOff + i].slot = mono ? monoBefore : (total - 1 - stereoBefore);
+            const OrbxLevelGeo& G = geo->lv[l];
+            const int slot = mono ? monoBefore : (total - 1 - stereoBefore);
+            K[G.kpOff + i].slot = slot;
+            // everything k_describe needs to know about this keypoint
+            OrbxDescWork wk;
+            wk.imgOff = (int)G.off; wk.pitch = G.pitch; wk.wh = G.w | (G.h << 16);
+            wk.cxy = __float2int_rn(rec.x) | (__float2int_rn(rec.y) << 16);
+            wk.slotLevel = slot | (l << 24);
+            wk.x = rec.x; wk.y = rec.y; wk.response = rec.response;
+            work[(long long)frame * geo->kpTotal + j] = wk;
         }
         __syncthreads();
         if (tid == 0) s_running = running + chunkMono;
@@ -1335,11 +1350,11 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 
 __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo* __restrict__ geo,
                                                               const uint8_t* __restrict__ pyr, long long frameStride,
-                                                              const OrbxLevelKp* __restrict__ levelKps,
-                                                              const int* __restrict__ kpCount,
+                                                              const OrbxDescWork* __restrict__ work, int kpTotal,
+                                                              unsigned int frameMagic,
+                                                              const int* __restrict__ counts,
                                                               orbx_keypoint* __restrict__ outKps,
-                                                              uint8_t* __restrict__ outDesc, int capacity,
-                                                              const uint8_t* __restrict__ kpLevel) {
+                                                              uint8_t* __restrict__ outDesc, int capacity) {
     // Per wave: the raw patch (later the blurred core) and the transposed row sums.  Nothing is shared between
     // waves, so a workgroup is ONE wave: a finished keypoint frees its 5.8 KB at once instead of waiting for the
     // slowest wave of a larger group (measured per 64 frames of 752 x 480: 109 us with 8 waves per workgroup, 98
@@ -1350,26 +1365,19 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
 
     // keypoints of one frame read the same few level images: keep a frame on one XCD
     const int logicalBlock = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int frame = logicalBlock / gridDim.x;
+    // frame = logicalBlock / gridDim.x through the host's reciprocal (exact for this grid, see enqueue_batch)
+    const int frame = frameMagic ? (int)__umulhi((unsigned int)logicalBlock, frameMagic) : logicalBlock / (int)gridDim.x;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int ordinal = (logicalBlock - frame * gridDim.x) * kDescWaves + wv;   // wave-uniform
-    const int nl = geo->nlevels;
-    // level of the keypoint record `ordinal` of a frame: host-built byte table
-    int level = -1, idx = 0;
-    if (ordinal < geo->kpTotal) {
-        level = kpLevel[ordinal];
-        idx = ordinal - geo->lv[level].kpOff;
-    }
-    bool active = level >= 0;
-    if (active) active = idx < kpCount[frame * nl + level];
-    const OrbxLevelGeo& G = geo->lv[active ? level : 0];
-    OrbxLevelKp kp;
-    kp.x = 0.f; kp.y = 0.f; kp.response = 0.f; kp.slot = -1;
-    if (active) kp = levelKps[(long long)frame * geo->kpTotal + G.kpOff + idx];
-    active = active && kp.slot >= 0 && kp.slot < capacity;
-    const uint8_t* img = pyr + (long long)frame * frameStride + G.off;
-    const int cx = __float2int_rn(kp.x), cy = __float2int_rn(kp.y);
+    const int ordinal = (logicalBlock - frame * gridDim.x) * kDescWaves + wv;   // wave-uniform: the frame's ordinal-th keypoint
+    // k_layout left one record per kept keypoint (and 0 keypoints for a frame that overflowed its output arrays)
+    const bool active = ordinal < counts[2 * frame];
+    const OrbxDescWork W = work[(long long)frame * kpTotal + (ordinal < kpTotal ? ordinal : 0)];
+    struct { int w, h, pitch, slot; } G;
+    G.w = W.wh & 0xFFFF; G.h = W.wh >> 16; G.pitch = W.pitch; G.slot = W.slotLevel & 0xFFFFFF;
+    const uint8_t* img = pyr + (long long)frame * frameStride + W.imgOff;
+    const int cx = W.cxy & 0xFFFF, cy = W.cxy >> 16;
     ORBX_DSTAMP_BEGIN();
+    if (kDescWaves == 1 && !active) return;
 
     uint8_t* rawBase = s_raw[wv];
     uint32_t* hor = s_hor[wv];
@@ -1516,15 +1524,17 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
         nib |= (uint32_t)(t[0] < t[1]) << j;
     }
     const uint32_t other = __shfl_xor(nib, 1);
-    const long long row = (long long)frame * capacity + kp.slot;
+    const long long row = (long long)frame * capacity + G.slot;
     if ((lane & 1) == 0) outDesc[row * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
     if (lane == 0) {
+        const int level = W.slotLevel >> 24;
+        const OrbxLevelGeo& L = geo->lv[level];
         orbx_keypoint k;
-        k.x = kp.x; k.y = kp.y;
-        if (level != 0) { k.x = __fmul_rn(kp.x, G.scale); k.y = __fmul_rn(kp.y, G.scale); }
-        k.size = G.patchSize;
+        k.x = W.x; k.y = W.y;
+        if (level != 0) { k.x = __fmul_rn(W.x, L.scale); k.y = __fmul_rn(W.y, L.scale); }
+        k.size = L.patchSize;
         k.angle = angle;
-        k.response = kp.response;
+        k.response = W.response;
         k.octave = level;
         k.class_id = -1;
         outKps[row] = k;
@@ -1557,8 +1567,8 @@ struct orbx_extractor {
     OrbxErr* d_err = nullptr;
     OrbxErr* h_err = nullptr;      // pinned
     orbx_rect* d_rects = nullptr;
-    int4* d_cells = nullptr;       // FAST cell table
-    uint8_t* d_kpLevel = nullptr;  // level of each keypoint record of a frame
+    OrbxFastCell* d_cells = nullptr;   // FAST cell table
+    OrbxDescWork* d_descWork = nullptr;   // per frame: k_layout's records for k_describe
     int *d_xofs = nullptr, *d_yofs = nullptr;
     uint32_t *d_xcoef = nullptr, *d_ycoef = nullptr;
     size_t tapAlloc = 0;
@@ -1643,7 +1653,7 @@ static void free_geo_buffers(orbx_extractor* ex) {
     hipFree(ex->d_xcoef); ex->d_xcoef = nullptr;
     hipFree(ex->d_ycoef); ex->d_ycoef = nullptr;
     hipFree(ex->d_cells); ex->d_cells = nullptr;
-    hipFree(ex->d_kpLevel); ex->d_kpLevel = nullptr;
+    hipFree(ex->d_descWork); ex->d_descWork = nullptr;
 }
 
 // Computes the level / cell / quadtree geometry for a w x h image and (re)allocates the
@@ -1771,8 +1781,8 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
     ORBX_HIP_TRY(hipMemcpy(ex->d_xcoef, xc.data(), tapX * sizeof(uint32_t), hipMemcpyHostToDevice));
     ORBX_HIP_TRY(hipMemcpy(ex->d_ycoef, yc.data(), tapY * sizeof(uint32_t), hipMemcpyHostToDevice));
     {
-        // per-cell constants of the FAST kernel (one int4 per processed cell, all levels)
-        std::vector<int4> cells(std::max(g.totalCells, 1));
+        // per-cell constants of the FAST kernel (one record per processed cell, all levels)
+        std::vector<OrbxFastCell> cells(std::max(g.totalCells, 1));
         for (int l = 0; l < P.nlevels; ++l) {
             const OrbxLevelGeo& L = g.lv[l];
             const int maxBX = L.w - kOrbxMinBorder, maxBY = L.h - kOrbxMinBorder;
@@ -1780,18 +1790,22 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
                 const int ci = c / L.nColsP, cj = c - ci * L.nColsP;
                 const int x0 = kOrbxMinBorder + cj * L.wCell, y0 = kOrbxMinBorder + ci * L.hCell;
                 const int x1 = std::min(x0 + L.wCell + 6, maxBX), y1 = std::min(y0 + L.hCell + 6, maxBY);
-                cells[L.cellBase + c] = make_int4(x0 | (y0 << 16), (x1 - x0) | ((y1 - y0) << 8) | (l << 16), c,
-                                                  L.nColsP * L.nRowsP - c);
+                OrbxFastCell& C = cells[L.cellBase + c];
+                C.xy = x0 | (y0 << 16);
+                C.dims = (x1 - x0) | ((y1 - y0) << 8) | (l << 16);
+                C.index = c;
+                C.apps = L.nColsP * L.nRowsP - c;
+                const long long tileOff = L.off + (long long)y0 * L.pitch + (x0 & ~3);
+                ORBX_REQUIRE(tileOff < (1ll << 31), "pyramid slab of one frame exceeds 2 GiB");
+                C.tileOff = (int)tileOff;
+                C.pitch = L.pitch;
+                C.pad0 = C.pad1 = 0;
             }
         }
-        ORBX_HIP_TRY(hipMalloc((void**)&ex->d_cells, cells.size() * sizeof(int4)));
-        ORBX_HIP_TRY(hipMemcpy(ex->d_cells, cells.data(), cells.size() * sizeof(int4), hipMemcpyHostToDevice));
-        // level of every keypoint record of a frame (describe kernel)
-        std::vector<uint8_t> kpLevel(std::max(g.kpTotal, 1), 0);
-        for (int l = 0; l < P.nlevels; ++l)
-            for (int i = 0; i < g.lv[l].kpCap; ++i) kpLevel[g.lv[l].kpOff + i] = (uint8_t)l;
-        ORBX_HIP_TRY(hipMalloc((void**)&ex->d_kpLevel, kpLevel.size()));
-        ORBX_HIP_TRY(hipMemcpy(ex->d_kpLevel, kpLevel.data(), kpLevel.size(), hipMemcpyHostToDevice));
+        ORBX_HIP_TRY(hipMalloc((void**)&ex->d_cells, cells.size() * sizeof(OrbxFastCell)));
+        ORBX_HIP_TRY(hipMemcpy(ex->d_cells, cells.data(), cells.size() * sizeof(OrbxFastCell), hipMemcpyHostToDevice));
+        // k_layout's records for k_describe: one per keypoint record of a frame
+        ORBX_HIP_TRY(hipMalloc((void**)&ex->d_descWork, B * (size_t)std::max(g.kpTotal, 1) * sizeof(OrbxDescWork)));
     }
     ORBX_HIP_TRY(hipMemcpy(ex->d_geo, &g, sizeof(g), hipMemcpyHostToDevice));
     ex->geo = g;
@@ -1943,25 +1957,34 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
                            ex->d_yofs, ex->d_ycoef, lanes, lanes == 1 ? 0xFFFFFFFFu : (uint32_t)(0x100000000ull / (unsigned)lanes));
     }
     mark(ex, st);
+    // the kernel divides its block index by the cells per frame with a reciprocal, m = floor(2^32 / d) + 1, exact
+    // while blocks * d < 2^32
+    const unsigned int cellMagic = ((unsigned long long)g.totalCells * nf) * g.totalCells < (1ull << 32) && g.totalCells > 1
+                                       ? (unsigned int)((1ull << 32) / (unsigned int)g.totalCells) + 1u : 0u;
     if (g.tileP == 48)
         hipLaunchKernelGGL(k_fast<48>, dim3(g.totalCells, nf), dim3(kFastThreads), (size_t)g.fastLds, st, ex->d_geo, ex->d_cells,
                            ex->d_pyr, g.pyrBytes, ex->d_cands, ex->d_candCount, ex->prm.ini_th_fast, ex->prm.min_th_fast,
-                           ex->d_rects, ndyn, ex->d_err);
+                           ex->d_rects, ndyn, ex->d_err, g.tileP, g.tileR, g.fastQueueOff, nl, cellMagic);
     else
         hipLaunchKernelGGL(k_fast<0>, dim3(g.totalCells, nf), dim3(kFastThreads), (size_t)g.fastLds, st, ex->d_geo, ex->d_cells,
                            ex->d_pyr, g.pyrBytes, ex->d_cands, ex->d_candCount, ex->prm.ini_th_fast, ex->prm.min_th_fast,
-                           ex->d_rects, ndyn, ex->d_err);
+                           ex->d_rects, ndyn, ex->d_err, g.tileP, g.tileR, g.fastQueueOff, nl, cellMagic);
     mark(ex, st);
     const size_t qtLds = (size_t)g.maxNodeCap * 56 + kQtThreads * sizeof(int);
     hipLaunchKernelGGL(k_quadtree, dim3(nl, nf), dim3(kQtThreads), qtLds, st, ex->d_geo, ex->d_cands, ex->d_candCount,
                        ex->d_keyNode, ex->d_levelKps, ex->d_kpCount, ex->d_err);
     mark(ex, st);
     hipLaunchKernelGGL(k_layout, dim3(nf), dim3(kLayThreads), 0, st, ex->d_geo, ex->d_levelKps, ex->d_kpCount, lap0, lap1,
-                       capacity, d_counts, ex->d_err);
+                       capacity, d_counts, ex->d_descWork, ex->d_err);
     mark(ex, st);
-    hipLaunchKernelGGL(k_describe, dim3((g.kpTotal + kDescWaves - 1) / kDescWaves, nf), dim3(64 * kDescWaves), 0, st,
-                       ex->d_geo, ex->d_pyr, g.pyrBytes, ex->d_levelKps, ex->d_kpCount, d_kps, d_desc, capacity,
-                       ex->d_kpLevel);
+    // A frame keeps at most min(kpTotal, capacity) keypoints: one wave each.  The kernel divides its block index
+    // by the grid width with a reciprocal, m = floor(2^32 / d) + 1, exact while blocks * d < 2^32.
+    const unsigned int descGrid = (unsigned int)((std::min(g.kpTotal, capacity) + kDescWaves - 1) / kDescWaves);
+    const unsigned int frameMagic =
+        ((unsigned long long)descGrid * nf) * descGrid < (1ull << 32) && descGrid > 1 ? (unsigned int)((1ull << 32) / descGrid) + 1u : 0u;
+    if (descGrid > 0)
+        hipLaunchKernelGGL(k_describe, dim3(descGrid, nf), dim3(64 * kDescWaves), 0, st, ex->d_geo, ex->d_pyr, g.pyrBytes,
+                           ex->d_descWork, g.kpTotal, frameMagic, d_counts, d_kps, d_desc, capacity);
     mark(ex, st);
     ORBX_HIP_TRY(hipGetLastError());
     ex->lastFrames = nf;

@@ -111,7 +111,13 @@
     X(145, "v_mad_u16", "v_mad_u16 %0, %0, %1, %0")                     \
     X(146, "v_add_u32 sdwa b0", "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0") \
     X(147, "v_max_i32 v,v2", "v_max_i32 %0, %1, %0")                    \
-    X(148, "v_cmp_gt_u32 + cndmask", "v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc")
+    X(148, "v_cmp_gt_u32 + cndmask", "v_cmp_gt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc") \
+    X(149, "lerp + add alternating", "v_lerp_u8 %0, %0, %1, %0\n\tv_add_u32 %0, %1, %0")           \
+    X(150, "add + add (same reg chain)", "v_add_u32 %0, %1, %0\n\tv_add_u32 %0, %1, %0")          \
+    X(151, "alignbyte + sub alternating", "v_alignbyte_b32 %0, %0, %1, 2\n\tv_sub_u32 %0, %1, %0") \
+    X(152, "add + s_nop 0", "v_add_u32 %0, %1, %0\n\ts_nop 0")                                    \
+    X(153, "add + s_mov (salu)", "v_add_u32 %0, %1, %0\n\ts_mov_b32 s20, 0")              \
+    X(154, "lerp + s_mov (salu)", "v_lerp_u8 %0, %0, %1, %0\n\ts_mov_b32 s20, 0")
 
 template <int KIND>
 __global__ __launch_bounds__(1024) void k2(unsigned* out, int iters, unsigned seed) {
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(1024) void k2(unsigned* out, int iters, unsigned se
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-#define X(id, name, text) if (KIND == id) asm volatile(text : "+v"(a[i]) : "v"(a[(i + 5) & 15]), "s"(s) : "vcc");
+#define X(id, name, text) if (KIND == id) asm volatile(text : "+v"(a[i]) : "v"(a[(i + 5) & 15]), "s"(s) : "vcc", "scc", "s20");
                 ROWS2(X)
 #undef X
             }
@@ -134,6 +140,37 @@ __global__ __launch_bounds__(1024) void k2(unsigned* out, int iters, unsigned se
 #pragma unroll
     for (int i = 0; i < 16; ++i) x ^= a[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+}
+
+// fully dependent chain: every instruction reads the result of the one before it
+template <int KIND>
+__global__ __launch_bounds__(1024) void k3(unsigned* out, int iters, unsigned seed) {
+    unsigned a = threadIdx.x * 2654435761u + seed, b = a * 7u + 1u;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            if (KIND == 0) asm volatile("v_add_u32 %0, %1, %0" : "+v"(a) : "v"(b));
+            if (KIND == 1) asm volatile("v_lerp_u8 %0, %0, %1, %0" : "+v"(a) : "v"(b));
+            if (KIND == 2) asm volatile("v_add_f32 %0, %1, %0" : "+v"(a) : "v"(b));
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a;
+}
+template <int KIND> void run3(const char* name, int blocks) {
+    const int threads = 1024, iters = 2000;
+    unsigned* d;
+    if (hipMalloc(&d, (size_t)blocks * threads * 4) != hipSuccess) { printf("hipMalloc failed\n"); exit(1); }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k3<KIND>, dim3(blocks), dim3(threads), 0, 0, d, 200, 1u);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k3<KIND>, dim3(blocks), dim3(threads), 0, 0, d, iters, 3u);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const int w = blocks / 256 * 4;
+    const double ns = (double)ms * 1e6 / ((double)iters * 64.0 * w);
+    printf("%-26s dependent chain, %d waves per SIMD: %7.3f ms   %.3f ns per wave-instruction per SIMD\n", name, w, ms, ns);
+    hipFree(d); hipEventDestroy(e0); hipEventDestroy(e1);
 }
 
 constexpr int kRows = 52;
@@ -211,12 +248,14 @@ template <int KIND> void run2(const char* name, int per) {
 }
 
 int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     if (argc < 2 || argv[1][0] == '1') {
 #define X(id, name, text) run<id>(name);
         ROWS(X)
 #undef X
     }
-#define X(id, name, text) run2<id>(name, id == 148 ? 2 : 1);
+    for (int blocks : {256, 512}) { run3<0>("v_add_u32", blocks); run3<1>("v_lerp_u8", blocks); run3<2>("v_add_f32", blocks); }
+#define X(id, name, text) run2<id>(name, id >= 148 && id <= 151 ? 2 : 1);
     ROWS2(X)
 #undef X
     return 0;
