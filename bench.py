@@ -6,6 +6,10 @@ are already resident in HBM: left + right ORBextractor::operator() (752x480, 100
 8 levels x 1.2, FAST 20/7) followed by Frame::ComputeStereoMatches -- the reference's EuRoC stereo configuration
 (Examples/Stereo/EuRoC.yaml; nFeatures = 1000 as in the metric's name, the yaml itself sets 1200).
 value = ORB frames (images) extracted per second, summed over all ranks.
+Consecutive steps are pipelined: they alternate between two sets of extractor handles, result arrays and stream
+pairs, so step i + 1 begins its extraction while step i is still describing and matching (frames arrive as a
+stream; nothing of a step is skipped, and the timed region ends with a device synchronisation).  The same K steps
+with a synchronisation after each one are timed as well ("value_one_step_at_a_time").
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): frames are sharded over the ranks,
 no data-path collective (weak scaling); the timing is barrier-bracketed and the max over ranks.
@@ -108,9 +112,9 @@ def cpu_baseline(n_pairs):
             "hamming_sample": "64 queries x 200 000 map descriptors, brute force top-2"}
 
 
-def pick_concurrent_stream(torch, dev, first, candidates=6, cycles=200000):
-    """Returns (stream, measured time of two overlapped spins / time of one spin) for the candidate
-    stream whose kernels overlap best with kernels on `first`."""
+def pick_concurrent_stream(torch, dev, chosen, candidates=6, cycles=200000):
+    """Returns (stream, time of one spin kernel on every stream at once / time of one spin) for the candidate
+    stream whose kernels overlap best with kernels on the streams already `chosen`."""
     def spin(streams):
         torch.cuda.synchronize()
         best = float("inf")
@@ -122,11 +126,11 @@ def pick_concurrent_stream(torch, dev, first, candidates=6, cycles=200000):
             torch.cuda.synchronize()
             best = min(best, time.perf_counter() - t0)
         return best
-    one = spin([first])
+    one = spin(chosen[:1])
     best_s, best_r = None, float("inf")
     for _ in range(candidates):
         c = torch.cuda.Stream(dev)
-        r = spin([first, c]) / one
+        r = spin(list(chosen) + [c]) / one
         if r < best_r:
             best_s, best_r = c, r
         if r < 1.25:
@@ -201,49 +205,73 @@ def main():
     del pairs
     dL = torch.from_numpy(left).to(dev)
     dR = torch.from_numpy(right).to(dev)
-    exL = A.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local)
-    exR = A.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local)
-    cap = exL.max_keypoints
-    mk = lambda: (torch.empty((B, cap, 28), dtype=torch.uint8, device=dev),
-                  torch.empty((B, cap, 32), dtype=torch.uint8, device=dev),
-                  torch.empty((B, 2), dtype=torch.int32, device=dev))
-    outL, outR = mk(), mk()
+    # Two sets of (left extractor, right extractor, output arrays): consecutive steps alternate between them, so
+    # that step i + 1 starts extracting while step i is still describing and matching (a handle's pyramid and the
+    # output arrays are read by the stereo matcher of their own step until it ends).  Every step does all of its
+    # work; the timed region ends with a device synchronisation.
+    cap = None
+    sets = []
+    for k in range(2):
+        eL = A.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local)
+        eR = A.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local)
+        cap = eL.max_keypoints
+        mk = lambda: (torch.empty((B, cap, 28), dtype=torch.uint8, device=dev),
+                      torch.empty((B, cap, 32), dtype=torch.uint8, device=dev),
+                      torch.empty((B, 2), dtype=torch.int32, device=dev))
+        sets.append({"exL": eL, "exR": eR, "outL": mk(), "outR": mk()})
+    exL, exR, outL, outR = sets[0]["exL"], sets[0]["exR"], sets[0]["outL"], sets[0]["outR"]
 
     # left and right extraction run on two HIP streams (the reference runs them on two
     # threads, Frame.cc:143-147); the stereo matcher waits for both.  HIP multiplexes streams
     # onto a few hardware queues and two streams that share a queue run strictly one after the
-    # other, so pick a pair that really overlaps (probed with two single-thread spin kernels).
+    # other, so pick streams that really overlap (probed with single-thread spin kernels).
     sL = torch.cuda.Stream(dev)
-    sR, overlap = pick_concurrent_stream(torch, dev, sL)
+    sR, overlap = pick_concurrent_stream(torch, dev, [sL])
+    sets[0]["sL"], sets[0]["sR"] = sL, sR
+    sets[1]["sL"], overlap3 = pick_concurrent_stream(torch, dev, [sL, sR])
+    sets[1]["sR"], overlap4 = pick_concurrent_stream(torch, dev, [sL, sR, sets[1]["sL"]])
 
-    def step():
-        cur = torch.cuda.current_stream(dev)
-        sL.wait_stream(cur); sR.wait_stream(cur)
-        with torch.cuda.stream(sL):
-            exL.extract_batch_device(dL, (0, 0), out=outL)
-        with torch.cuda.stream(sR):
-            exR.extract_batch_device(dR, (0, 0), out=outR)
-        sL.wait_stream(sR)
-        with torch.cuda.stream(sL):
-            r = A.compute_stereo_matches_device(exL, exR, outL, outR, MBF, MBF / FX)
-        cur.wait_stream(sL)
+    def step(i=0):
+        S = sets[i % 2]
+        a, b = S["sL"], S["sR"]
+        b.wait_stream(a)             # the set's previous stereo match (on a) read the right handle's pyramid and arrays
+        with torch.cuda.stream(a):
+            S["exL"].extract_batch_device(dL, (0, 0), out=S["outL"])
+        with torch.cuda.stream(b):
+            S["exR"].extract_batch_device(dR, (0, 0), out=S["outR"])
+        a.wait_stream(b)
+        with torch.cuda.stream(a):
+            r = A.compute_stereo_matches_device(S["exL"], S["exR"], S["outL"], S["outR"], MBF, MBF / FX)
         return r
+
+    def check_status():
+        for S in sets:
+            S["exL"].status(); S["exR"].status()
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(max(args.warmup, 1)):
-        ur, depth = step()
+    for w in range(2 * max(args.warmup, 1)):
+        step(w)
         torch.cuda.synchronize()
-        exL.status(); exR.status()        # a capacity overflow regrows the buffers during warm-up
+        check_status()                    # a capacity overflow regrows the buffers during warm-up
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ur, depth = step()
+    for i in range(args.steps):
+        r = step(i)
+        if i % 2 == 0:
+            ur, depth = r                 # set 0's result arrays (checked below against set 0's counts)
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
-    exL.status(); exR.status()
+    check_status()
+    # the same K steps one at a time (a device synchronisation after each): what one step costs without its neighbours
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+        torch.cuda.synchronize()
+    dt_serial = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -256,8 +284,8 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
+        step(0)
+        torch.cuda.synchronize()
     dt_events = time.perf_counter() - t1
     tL, nL = exL.get_timing()
     tR, nR = exR.get_timing()
@@ -349,6 +377,11 @@ def main():
                                 "two-stream steps with hipEvents between the kernels",
                          "ms_per_step_with_events": 1e3 * dt_events / args.steps},
         "stream_overlap_ratio": overlap,
+        "stream_overlap_ratio_4": overlap4,
+        "pipelining": "consecutive steps alternate between two sets of extractor handles and streams; step i + 1 "
+                      "starts while step i is still describing and matching",
+        "ms_per_step_one_at_a_time": 1e3 * dt_serial / args.steps,
+        "value_one_step_at_a_time": frames_per_step * args.steps / dt_serial,
     }
 
     if valu is not None:
@@ -376,7 +409,7 @@ def main():
         outs = [mkH(), mkH()]
         outH = outs[0]
         sA = torch.cuda.Stream(dev)
-        sB, overlapH = pick_concurrent_stream(torch, dev, sA)
+        sB, overlapH = pick_concurrent_stream(torch, dev, [sA])
         streams = [sA, sB]
         for _ in range(2):
             for k in range(2):
