@@ -89,7 +89,8 @@ struct alignas(32) OrbxFastCell {
     int apps;                // cells from this one to the level's last
     int tileOff;             // byte offset, inside a frame's pyramid slab, of the tile's first (4-byte aligned) column
     int pitch;               // row pitch of the level
-    int pad0, pad1;
+    int bands;               // quick-reject lane layout: dword columns | bands << 8 | rows per band << 16 | both waves << 24
+    int colRcp;              // floor(65536 / columns) + 1: lane / columns = (lane * colRcp) >> 16 for lane < 128
 };
 
 // What k_describe needs to know about one kept keypoint, written by k_layout for the j-th keypoint of a frame in

@@ -457,7 +457,6 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     const int levelPitch = CI.pitch;
     const int tid = threadIdx.x;
     const int xa = x0 & ~3, ox = x0 - xa;
-    const int rowDwords = (x0 + tw - xa + 3) >> 2;      // <= P / 4
 
     ORBX_STAMP_BEGIN();
     if (tid == 0) { s_nQueue = 0; s_nIni = 0; s_nMin = 0; s_nKeep = 0; }
@@ -492,7 +491,8 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
             const int RD = P >> 2;
             const int rowsPerPass = kFastThreads / RD;
             const int row = tid / RD, xd = tid - row * RD;
-            if (row < rowsPerPass && xd < rowDwords) {
+            // (whole rows, like the 16-byte path: the quick reject needs every byte of a row to be a pixel)
+            if (row < rowsPerPass) {
                 const uint8_t* src = tileSrc + (long long)row * levelPitch + 4 * xd;
                 uint8_t* dstT = tile + row * P + 4 * xd;
                 const int planeBytes = P * R;
@@ -537,9 +537,10 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
         // further 4 pixels cost three LDS dword reads.  Survivors are collected in a per-lane bit mask and queued at the end.
         // One wave does the whole cell when its bands fit one 8-row pass (fewer instructions than two waves with
         // shorter bands); cells whose bands would be taller are shared by both waves.
-        const int dFirst = (ox + 3) >> 2, dLast = (ox + 3 + iw - 1) >> 2;     // tile dword columns with testable pixels
-        const int ncol = dLast - dFirst + 1;
-        const bool bothWaves = fast_band_rows(ncol, ih, 64) > 8;
+        // (the lane layout comes with the cell record: columns, bands, rows per band, one wave or both)
+        const int dFirst = (ox + 3) >> 2;                                     // first tile dword column with testable pixels
+        const int ncol = CI.bands & 255;
+        const bool bothWaves = (CI.bands >> 24) != 0;
         const int qrLanes = bothWaves ? 128 : 64;
         if (tid < qrLanes) {
             const int t1 = lowTh + 1;                                  // a - b >= t1
@@ -548,9 +549,9 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
             uint32_t KB0 = (uint32_t)(128 - max(tq, 1)) * 0x01010101u;     // 128 - tq per byte
             uint32_t KB0H = KB0 | 0x80808080u;
             asm volatile("" : "+v"(KB0), "+v"(KB0H));                  // vector registers: a scalar operand halves the issue rate
-            const int bands = max(1, min(qrLanes / ncol, ih));
-            const int bandRows = (ih + bands - 1) / bands;
-            const int band = tid / ncol, d = dFirst + (tid - band * ncol);
+            const int bands = (CI.bands >> 8) & 255;
+            const int bandRows = (CI.bands >> 16) & 255;
+            const int band = (tid * CI.colRcp) >> 16, d = dFirst + (tid - band * ncol);
             const bool laneOn = band < bands;
             const int yBeg = 3 + band * bandRows;
             const int yEnd = laneOn ? min(yBeg + bandRows, 3 + ih) : 0;
@@ -566,9 +567,14 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
                 const int rows = min(8, bandRows - chunk);             // uniform
                 const uint32_t* c = reinterpret_cast<const uint32_t*>(coarse + (laneOn ? yc : 3) * P) + (laneOn ? d : 1);
                 const int PD = P >> 2;                                 // row pitch in dwords
-                // the dword columns left and right of the lane's own (clamped to the row: a clamped column is only
-                // ever the source of bytes that no testable pixel of this lane uses)
-                const int dl = (laneOn && d > 0) ? -1 : 0, dr = (laneOn && d + 1 < PD) ? 1 : 0;
+                // the dword columns left and right of the lane's own, at fixed offsets from it.  At the ends of a row
+                // they are the neighbouring row's dwords (or, around the tile, the strength tile's last dword and the 16
+                // spare bytes behind the coarse tile): such a column is only ever the source of bytes that no testable
+                // pixel of this lane uses, since a testable pixel's whole circle lies inside its tile row.  What those
+                // bytes hold still matters on the LEFT: they land below the used bytes of the shifted dword, and a byte
+                // above 127 there would carry into them.  Every byte the left column can come from is a coarse pixel:
+                // the tile load fills whole rows, and the rows whose left column is used start at row 1.
+                constexpr int dl = -1, dr = 1;
                 // rows y-3 .. y+3 of the three columns, rotated through registers
                 uint32_t C0 = c[-3 * PD], C1 = c[-2 * PD], C2 = c[-PD], C3 = c[0], C4 = c[PD], C5 = c[2 * PD], C6 = c[3 * PD];
                 uint32_t L0 = c[-3 * PD + dl], L1 = c[-2 * PD + dl], L2 = c[-PD + dl], L3 = c[dl], L4 = c[PD + dl],
@@ -1736,8 +1742,9 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
                 maxBandRows = std::max(maxBandRows, rows1 > 8 ? fast_band_rows(ncol, ih, 128) : rows1);
             }
         const int plane = g.tileP * g.tileR, queueBytes = 2 * ((mw - 6) * (mh - 6) + 4);
-        if (maxBandRows <= 8) { g.fastQueueOff = 2 * plane; g.fastLds = 2 * plane + std::max(plane, queueBytes); }
-        else { g.fastQueueOff = 3 * plane; g.fastLds = 3 * plane + queueBytes; }
+        // (+ 16 bytes behind the coarse tile: the quick reject reads one dword past a row's end)
+        if (maxBandRows <= 8) { g.fastQueueOff = 2 * plane; g.fastLds = 2 * plane + std::max(plane + 16, queueBytes); }
+        else { g.fastQueueOff = 3 * plane + 16; g.fastLds = 3 * plane + 16 + queueBytes; }
     }
 
     {
@@ -1799,7 +1806,19 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
                 ORBX_REQUIRE(tileOff < (1ll << 31), "pyramid slab of one frame exceeds 2 GiB");
                 C.tileOff = (int)tileOff;
                 C.pitch = L.pitch;
-                C.pad0 = C.pad1 = 0;
+                // lane layout of the quick reject (k_fast): one lane per (band of rows, dword column)
+                const int ox = x0 & 3, iw = x1 - x0 - 6, ih = y1 - y0 - 6;
+                if (iw > 0 && ih > 0) {
+                    const int ncol = ((ox + 3 + iw - 1) >> 2) - ((ox + 3) >> 2) + 1;
+                    const bool both = fast_band_rows(ncol, ih, 64) > 8;
+                    const int lanes = both ? 128 : 64;
+                    const int q = lanes / ncol, nb = q < 1 ? 1 : (q < ih ? q : ih);
+                    C.bands = ncol | (nb << 8) | (fast_band_rows(ncol, ih, lanes) << 16) | ((both ? 1 : 0) << 24);
+                    C.colRcp = 65536 / ncol + 1;
+                } else {
+                    C.bands = 1 | (1 << 8) | (1 << 16);
+                    C.colRcp = 65536 + 1;
+                }
             }
         }
         ORBX_HIP_TRY(hipMalloc((void**)&ex->d_cells, cells.size() * sizeof(OrbxFastCell)));

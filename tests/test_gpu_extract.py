@@ -70,22 +70,23 @@ def test_thresholds(oracle, ini, mn):
     _same(*o(img, (0, 0)), *g(img, (0, 0)))
 
 
+@pytest.mark.parametrize("w,h", [(640, 480), (640, 400)])     # the second size has cells wider than the 48-byte tile pitch
 @pytest.mark.parametrize("ini,mn", [(20, 7), (3, 1), (2, 0), (0, 0), (255, 200), (120, 127)])
-def test_saturated_regions_and_extreme_thresholds(oracle, ini, mn):
+def test_saturated_regions_and_extreme_thresholds(oracle, ini, mn, w, h):
     # The FAST kernel's first-stage test works on halved pixel values with byte-wise carries kept out by clamps
     # near 0 and 255, passes everything when the threshold is below its resolution and clamps thresholds above
     # it: pixels at both ends of the range, with every kind of threshold, against the oracle.
     A = _gpu()
     rng = np.random.default_rng(77)
-    img = synth.scene(640, 480, 33, n_prims=150, noise_sigma=1.5).astype(np.int32)
+    img = synth.scene(w, h, 33, n_prims=150, noise_sigma=1.5).astype(np.int32)
     img[:160] = np.clip(img[:160] + 150, 0, 255)          # bright band, large parts at 255
-    img[320:] = np.clip(img[320:] - 150, 0, 255)          # dark band, large parts at 0
+    img[h - 160:] = np.clip(img[h - 160:] - 150, 0, 255)  # dark band, large parts at 0
     img[200:280, 100:500] = rng.integers(0, 2, (80, 400)) * 255    # full-range salt and pepper
     img[100:140, 300:600] = 255 - rng.integers(0, 3, (40, 300))    # near-saturated noise
-    img[400:440, 50:350] = rng.integers(0, 3, (40, 300))
+    img[h - 80:h - 40, 50:350] = rng.integers(0, 3, (40, 300))
     img = img.astype(np.uint8)
     o = oracle.Extractor(600, 1.2, 8, ini, mn)
-    g = A.ORBextractor(600, 1.2, 8, ini, mn, max_width=640, max_height=480)
+    g = A.ORBextractor(600, 1.2, 8, ini, mn, max_width=w, max_height=h)
     _same(*o(img, (0, 0)), *g(img, (0, 0)))
     g.close()
 
