@@ -318,6 +318,18 @@ __host__ __device__ __forceinline__ int fast_band_rows(int ncol, int ih, int lan
     return (ih + bands - 1) / bands;
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave (all lanes must be active): shifts by 1, 2, 4, 8 inside the rows of
+// 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3.
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast31 into rows 2 and 3
+    return v;
+}
+
 __device__ __forceinline__ int score_at(int strength, int th) { return strength > th ? strength - 1 : 0; }
 
 // cv::Rect2i::contains(Point2i(pt)): the float point converts with round-half-even.
@@ -635,10 +647,18 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
                     const uint32_t keepBits = (((1u << (rowBit0 + nvalid)) - 1u) & 0xFFu) * 0x01010101u;
                     m = passAll ? ((((1u << nvalid) - 1u) << rowBit0) * (((valid >> 7) & 0x01010101u))) : (mask & keepBits);
                 }
+                // Queue slots: a prefix sum over the wave's lanes (cross-lane moves) and ONE atomic per wave.  (Left as a
+                // per-lane atomicAdd, the compiler serialises the lanes: nine scalar instructions for every lane that
+                // has a survivor.)
                 const int cnt = __popc(m);
+                const int incl = wave_incl_scan_i32(cnt);
+                const int waveTotal = __builtin_amdgcn_readlane(incl, 63);
                 if (bothWaves) __syncthreads();     // the queue may lie on the coarse tile the other wave still reads
+                int waveBase = 0;
+                if ((tid & 63) == 0 && waveTotal) waveBase = atomicAdd(&s_nQueue, waveTotal);
+                waveBase = __builtin_amdgcn_readfirstlane(waveBase);
                 if (cnt) {
-                    int base = atomicAdd(&s_nQueue, cnt);
+                    int base = waveBase + incl - cnt;
                     while (m) {
                         const int i = __ffs(m) - 1;       // byte i >> 3 = pixel of the dword, bit i & 7 = rowBit0 + row of the chunk
                         m &= m - 1;
