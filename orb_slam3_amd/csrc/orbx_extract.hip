@@ -318,6 +318,18 @@ __host__ __device__ __forceinline__ int fast_band_rows(int ncol, int ih, int lan
     return (ih + bands - 1) / bands;
 }
 
+// Sum of a value over the 64 lanes of the wave, returned in every lane (as a scalar): four cross-lane adds inside the
+// rows of 16 lanes, two row broadcasts, one read of lane 63 -- data-parallel-primitive moves, no LDS round trips.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror: every lane holds its row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // Inclusive prefix sum over the 64 lanes of a wave (all lanes must be active): shifts by 1, 2, 4, 8 inside the rows of
 // 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3.
 __device__ __forceinline__ int wave_incl_scan_i32(int v) {
@@ -1041,13 +1053,14 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
         __syncthreads();
 
         // (4) write the new generation
+        int nexpMine = 0;
         for (int p = tid; p < size; p += kQtThreads) {
             if (base[p] < 0) {
                 const int np = total + scanv[p];
                 nbox[np] = box[p]; ncnt[np] = cnt[p];
                 child[4 * p] = np;
             } else {
-                int seq = base[p], nexp = 0;
+                int seq = base[p], nexp = 0;   // (nexp: children of this node that can be split again)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int c = child[4 * p + q];
@@ -1059,8 +1072,13 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
                         nexp += (c > 1);
                     }
                 }
-                if (nexp) atomicAdd(&s_nExp, nexp);
+                nexpMine += nexp;
             }
+        }
+        {
+            // one atomic per wave (a per-lane atomicAdd of differing values is serialised lane by lane by the compiler)
+            const int waveExp = wave_sum_i32(nexpMine);
+            if ((tid & 63) == 0 && waveExp) atomicAdd(&s_nExp, waveExp);
         }
         __syncthreads();
         // (5) move the keys
@@ -1360,18 +1378,6 @@ __device__ __forceinline__ void hblur_rows(const uint8_t* __restrict__ rawBase, 
         for (int k = 0; k < 8; ++k)
             if (c0 + k < kBlurW) dst[k * kHorTPD] = sums[0][k] | (sums[1][k] << 16);     // a row sum is < 65536
     }
-}
-
-// Sum of a value over the 64 lanes of the wave, returned in every lane (as a scalar): four cross-lane adds inside the
-// rows of 16 lanes, two row broadcasts, one read of lane 63 -- data-parallel-primitive moves, no LDS round trips.
-__device__ __forceinline__ int wave_sum_i32(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror: every lane holds its row's sum
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast31 into rows 2 and 3
-    return __builtin_amdgcn_readlane(v, 63);
 }
 
 __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo* __restrict__ geo,
