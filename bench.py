@@ -211,7 +211,10 @@ def main():
     # work; the timed region ends with a device synchronisation.
     cap = None
     sets = []
-    for k in range(2):
+    # (ORBX_BENCH_SETS overrides the number of sets for experiments: 1 set 246 k, 2 sets 264 k, 3 sets 262 k, 4 sets 269 k
+    # frames/s -- HIP offers four hardware queues, two sets fill them)
+    NSETS = max(1, int(os.environ.get("ORBX_BENCH_SETS", "2")))
+    for k in range(NSETS):
         eL = A.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local)
         eR = A.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=B, device=local)
         cap = eL.max_keypoints
@@ -228,11 +231,14 @@ def main():
     sL = torch.cuda.Stream(dev)
     sR, overlap = pick_concurrent_stream(torch, dev, [sL])
     sets[0]["sL"], sets[0]["sR"] = sL, sR
-    sets[1]["sL"], overlap3 = pick_concurrent_stream(torch, dev, [sL, sR])
-    sets[1]["sR"], overlap4 = pick_concurrent_stream(torch, dev, [sL, sR, sets[1]["sL"]])
+    chosen, overlap4 = [sL, sR], overlap
+    for k in range(1, NSETS):
+        for name in ("sL", "sR"):
+            sets[k][name], overlap4 = pick_concurrent_stream(torch, dev, chosen)
+            chosen.append(sets[k][name])
 
     def step(i=0):
-        S = sets[i % 2]
+        S = sets[i % NSETS]
         a, b = S["sL"], S["sR"]
         b.wait_stream(a)             # the set's previous stereo match (on a) read the right handle's pyramid and arrays
         with torch.cuda.stream(a):
@@ -252,7 +258,7 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for w in range(2 * max(args.warmup, 1)):
+    for w in range(NSETS * max(args.warmup, 1)):
         step(w)
         torch.cuda.synchronize()
         check_status()                    # a capacity overflow regrows the buffers during warm-up
@@ -260,7 +266,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         r = step(i)
-        if i % 2 == 0:
+        if i % NSETS == 0:
             ur, depth = r                 # set 0's result arrays (checked below against set 0's counts)
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
