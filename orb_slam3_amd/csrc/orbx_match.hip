@@ -545,7 +545,9 @@ struct OrbxPyrView {
     long long frameStride;      // bytes between frames (same for both: same geometry)
 };
 
-constexpr int kStWaves = 8;          // waves per workgroup
+// Waves per workgroup.  The waves share nothing, and a small workgroup finds room on a compute unit that other
+// streams' kernels keep full (8 waves per workgroup: 266 k frames/s in the pipelined benchmark, 2 or 1: 270 k).
+constexpr int kStWaves = 2;
 constexpr int kStPerWave = 4;        // left keypoints handled by one wave, one after the other
 constexpr int kStBuckets = 256;      // row buckets of the staged keypoints (multiple of 64)
 
