@@ -828,8 +828,14 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
 // split from the back until the list holds N nodes.  The per-node winner is the key with
 // the highest response, the earliest in emission order among equals.
 // ======================================================================================
-constexpr int kQtThreads = 512;
-constexpr int kQtRegKeys = 8;     // keys per thread whose position and node stay in registers
+// Threads per workgroup: a template parameter of the kernel, chosen per handle (qt_threads_for).  Large workgroups
+// finish a big level sooner, small ones are placed sooner on compute units that other streams' kernels keep full.
+constexpr int kQtThreadsMax = 512;
+// keys per thread whose position and node stay in registers (4096 keys per workgroup, at most 16 per thread)
+__host__ __device__ constexpr int qt_reg_keys(int threads) { return 4096 / threads < 16 ? 4096 / threads : 16; }
+// Measured in the pipelined benchmark (two handle sets, four streams), frames/s with 128 / 256 / 512 threads:
+// 752x480 with 1000 features 284 k / 277 k / 274 k, 1920x1080 with 5000 features 46.5 k / 52.5 k / 53.3 k.
+static inline int qt_threads_for(int nfeatures) { return nfeatures <= 1500 ? 128 : (nfeatures <= 3000 ? 256 : 512); }
 
 struct QtBox { short ulx, uly, brx, bry; };
 
@@ -849,6 +855,7 @@ __device__ __forceinline__ QtBox qt_child_box(const QtBox b, int q) {
 
 // Exclusive scan of v[0..n) (in place) by the whole workgroup; returns the total.
 // Per-thread chunk sums, a shuffle scan inside each wave, then the wave totals (tmp: one int per wave).
+template <int kQtThreads>
 __device__ int qt_block_scan(int* v, int n, int* tmp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = (n + kQtThreads - 1) / kQtThreads;
@@ -876,12 +883,14 @@ __device__ int qt_block_scan(int* v, int n, int* tmp) {
     return total;
 }
 
+template <int kQtThreads>
 __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __restrict__ geo,
                                                          const OrbxCand* __restrict__ cands,
                                                          const int* __restrict__ candCount,
                                                          uint16_t* __restrict__ keyNode,
                                                          OrbxLevelKp* __restrict__ levelKps,
                                                          int* __restrict__ kpCount, OrbxErr* __restrict__ err) {
+    constexpr int kQtRegKeys = qt_reg_keys(kQtThreads);
     extern __shared__ __align__(16) unsigned char qt_smem[];
     const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
     const int nl = geo->nlevels;
@@ -990,7 +999,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
                 scanv[p] = v;
             }
             __syncthreads();
-            const int both = qt_block_scan(scanv, size, tmp);
+            const int both = qt_block_scan<kQtThreads>(scanv, size, tmp);
             total = both & 0xFFFF; kept = both >> 16;
             for (int p = tid; p < size; p += kQtThreads) {
                 const int v = scanv[p];
@@ -1041,7 +1050,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
         if (careful) {
             for (int p = tid; p < size; p += kQtThreads) scanv[p] = (base[p] < 0) ? 1 : 0;
             __syncthreads();
-            kept = qt_block_scan(scanv, size, tmp);
+            kept = qt_block_scan<kQtThreads>(scanv, size, tmp);
         }
         const int newSize = total + kept;
         if (newSize > cap) {   // cannot happen for a consistent geometry; never write out of bounds
@@ -1774,13 +1783,16 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
     }
 
     {
-        const size_t qtLds = (size_t)maxNode * 56 + kQtThreads * sizeof(int);
+        const size_t qtLds = (size_t)maxNode * 56 + kQtThreadsMax * sizeof(int);
         int ldsMax = 0;
         ORBX_HIP_TRY(hipDeviceGetAttribute(&ldsMax, hipDeviceAttributeMaxSharedMemoryPerBlock, ex->device));
         ORBX_REQUIRE((long long)qtLds + 2048 <= ldsMax, "quadtree needs %zu bytes of LDS, the device offers %d", qtLds, ldsMax);
         if (qtLds > 32 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)qtLds);
+            const int qtThreads = qt_threads_for(P.nfeatures);
+            const void* fn = qtThreads == 128 ? reinterpret_cast<const void*>(k_quadtree<128>)
+                             : qtThreads == 256 ? reinterpret_cast<const void*>(k_quadtree<256>)
+                                                : reinterpret_cast<const void*>(k_quadtree<512>);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qtLds);
             if (e != hipSuccess) {
                 orbx_set_error("cannot raise the dynamic LDS limit of the quadtree kernel to %zu (device max %d): %s", qtLds,
                                ldsMax, hipGetErrorString(e));
@@ -2015,9 +2027,20 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
                            ex->d_pyr, g.pyrBytes, ex->d_cands, ex->d_candCount, ex->prm.ini_th_fast, ex->prm.min_th_fast,
                            ex->d_rects, ndyn, ex->d_err, g.tileP, g.tileR, g.fastQueueOff, nl, cellMagic);
     mark(ex, st);
-    const size_t qtLds = (size_t)g.maxNodeCap * 56 + kQtThreads * sizeof(int);
-    hipLaunchKernelGGL(k_quadtree, dim3(nl, nf), dim3(kQtThreads), qtLds, st, ex->d_geo, ex->d_cands, ex->d_candCount,
-                       ex->d_keyNode, ex->d_levelKps, ex->d_kpCount, ex->d_err);
+    const size_t qtLds = (size_t)g.maxNodeCap * 56 + kQtThreadsMax * sizeof(int);
+    switch (qt_threads_for(ex->prm.nfeatures)) {
+        case 128:
+            hipLaunchKernelGGL(k_quadtree<128>, dim3(nl, nf), dim3(128), qtLds, st, ex->d_geo, ex->d_cands, ex->d_candCount,
+                               ex->d_keyNode, ex->d_levelKps, ex->d_kpCount, ex->d_err);
+            break;
+        case 256:
+            hipLaunchKernelGGL(k_quadtree<256>, dim3(nl, nf), dim3(256), qtLds, st, ex->d_geo, ex->d_cands, ex->d_candCount,
+                               ex->d_keyNode, ex->d_levelKps, ex->d_kpCount, ex->d_err);
+            break;
+        default:
+            hipLaunchKernelGGL(k_quadtree<512>, dim3(nl, nf), dim3(512), qtLds, st, ex->d_geo, ex->d_cands, ex->d_candCount,
+                               ex->d_keyNode, ex->d_levelKps, ex->d_kpCount, ex->d_err);
+    }
     mark(ex, st);
     hipLaunchKernelGGL(k_layout, dim3(nf), dim3(kLayThreads), 0, st, ex->d_geo, ex->d_levelKps, ex->d_kpCount, lap0, lap1,
                        capacity, d_counts, ex->d_descWork, ex->d_err);
@@ -2344,7 +2367,7 @@ extern "C" orbx_status orbx_debug_level_keypoints(orbx_extractor* ex, int frame,
 // ---- stage tap: the workgroup sort on its own -------------------------------------------
 constexpr int kSortTapMax = 2048;
 
-__global__ __launch_bounds__(kQtThreads) void k_sort_tap(unsigned long long* __restrict__ data, const int* __restrict__ offsets) {
+__global__ __launch_bounds__(kQtThreadsMax) void k_sort_tap(unsigned long long* __restrict__ data, const int* __restrict__ offsets) {
     extern __shared__ __align__(16) unsigned char st_smem[];
     const int b = blockIdx.x, n = offsets[b + 1] - offsets[b];
     unsigned long long* v = reinterpret_cast<unsigned long long*>(st_smem);
@@ -2353,11 +2376,11 @@ __global__ __launch_bounds__(kQtThreads) void k_sort_tap(unsigned long long* __r
     int* posR = posL + kSortTapMax;
     int* segs = posR + kSortTapMax;     // 6 * (kSortTapMax / 17 + 1) ints
     unsigned long long* g = data + offsets[b];
-    for (int i = threadIdx.x; i < n; i += kQtThreads) v[i] = g[i];
+    for (int i = threadIdx.x; i < n; i += kQtThreadsMax) v[i] = g[i];
     __syncthreads();
     orbx_sort::block_sort(v, n, segs, posL, posR, out);
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += kQtThreads) g[i] = v[i];
+    for (int i = threadIdx.x; i < n; i += kQtThreadsMax) g[i] = v[i];
 }
 
 extern "C" orbx_status orbx_debug_wave_sort(const uint64_t* elems, const int* offsets, int n_arrays,
@@ -2379,7 +2402,7 @@ extern "C" orbx_status orbx_debug_wave_sort(const uint64_t* elems, const int* of
     hipError_t e = hipMemcpy(d_data, elems, total * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_off, offsets, (n_arrays + 1) * sizeof(int), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_sort_tap, dim3(n_arrays), dim3(kQtThreads), kSortTapMax * 24 + 6 * (kSortTapMax / 17 + 1) * sizeof(int), 0, d_data, d_off);
+        hipLaunchKernelGGL(k_sort_tap, dim3(n_arrays), dim3(kQtThreadsMax), kSortTapMax * 24 + 6 * (kSortTapMax / 17 + 1) * sizeof(int), 0, d_data, d_off);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(device_sorted, d_data, total * 8, hipMemcpyDeviceToHost);
