@@ -567,7 +567,8 @@ __device__ __forceinline__ int stereo_bucket_shift(int nRows) {
     return shift;
 }
 
-__global__ __launch_bounds__(512) void k_stereo_prep(const OrbxFrameGeo* __restrict__ geo,
+constexpr int kStPrepThreads = 128;   // one small workgroup per frame (a thousand keypoints): placed at once beside other kernels
+__global__ __launch_bounds__(kStPrepThreads) void k_stereo_prep(const OrbxFrameGeo* __restrict__ geo,
                                                      const orbx_keypoint* __restrict__ kpsR,
                                                      const int* __restrict__ countsR, int capacity, OrbxStereoSorted out) {
     __shared__ int s_start[kStBuckets + 1];
@@ -577,10 +578,10 @@ __global__ __launch_bounds__(512) void k_stereo_prep(const OrbxFrameGeo* __restr
     const int nRows = geo->lv[0].h;
     const int shift = stereo_bucket_shift(nRows);
     const orbx_keypoint* KR = kpsR + (long long)frame * capacity;
-    for (int i = tid; i < kStBuckets; i += 512) { s_start[i + 1] = 0; s_fill[i] = 0; }
+    for (int i = tid; i < kStBuckets; i += kStPrepThreads) { s_start[i + 1] = 0; s_fill[i] = 0; }
     if (tid == 0) s_start[0] = 0;
     __syncthreads();
-    for (int j = tid; j < nR; j += 512) {
+    for (int j = tid; j < nR; j += kStPrepThreads) {
         const int b = min(max((int)KR[j].y, 0), nRows - 1) >> shift;
         atomicAdd(&s_start[b + 1], 1);
     }
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(512) void k_stereo_prep(const OrbxFrameGeo* __restr
     uint32_t* rows = out.rows + (long long)frame * capacity;
     float* xs = out.x + (long long)frame * capacity;
     uint32_t* oi = out.octIdx + (long long)frame * capacity;
-    for (int j = tid; j < nR; j += 512) {
+    for (int j = tid; j < nR; j += kStPrepThreads) {
         const orbx_keypoint kr = KR[j];
         const int b = min(max((int)kr.y, 0), nRows - 1) >> shift;
         const int slot = s_start[b] + atomicAdd(&s_fill[b], 1);
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(512) void k_stereo_prep(const OrbxFrameGeo* __restr
         xs[slot] = kr.x;
         oi[slot] = ((uint32_t)kr.octave << 20) | (uint32_t)j;
     }
-    for (int i = tid; i <= kStBuckets; i += 512) out.start[(long long)frame * (kStBuckets + 1) + i] = s_start[i];
+    for (int i = tid; i <= kStBuckets; i += kStPrepThreads) out.start[(long long)frame * (kStBuckets + 1) + i] = s_start[i];
 }
 
 __global__ __launch_bounds__(64 * kStWaves) void k_stereo_rows(const OrbxFrameGeo* __restrict__ geo, OrbxPyrView pv,
@@ -942,7 +943,7 @@ extern "C" orbx_status orbx_stereo_match_batch_device(orbx_extractor* left, orbx
     sorted.x = (float*)(scratch + (size_t)n_frames * perFrame * 2);
     sorted.octIdx = (uint32_t*)(scratch + (size_t)n_frames * perFrame * 3);
     sorted.start = (int*)(scratch + (size_t)n_frames * perFrame * 4);
-    hipLaunchKernelGGL(k_stereo_prep, dim3(n_frames), dim3(512), 0, st, orbx_internal_geo_device(left), d_kps_right,
+    hipLaunchKernelGGL(k_stereo_prep, dim3(n_frames), dim3(kStPrepThreads), 0, st, orbx_internal_geo_device(left), d_kps_right,
                        d_counts_right, capacity, sorted);
     hipLaunchKernelGGL(k_stereo_rows, dim3((capacity + kStWaves * kStPerWave - 1) / (kStWaves * kStPerWave), n_frames),
                        dim3(64 * kStWaves), 0, st, orbx_internal_geo_device(left), pv,
