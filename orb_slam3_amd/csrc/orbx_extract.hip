@@ -83,9 +83,11 @@ struct OrbxErr {
 // as one int4 of source offsets and one uint4 of packed (a0 | a1 << 16) coefficients.
 // ======================================================================================
 #ifndef ORBX_PYR_THREADS
-#define ORBX_PYR_THREADS 256
+#define ORBX_PYR_THREADS 128
 #endif
-constexpr int kPyrThreads = ORBX_PYR_THREADS;   // threads per workgroup of the level-0 copy and the resize kernels
+// Threads per workgroup of the level-0 copy and the resize kernels.  Pipelined benchmark at 752x480: 64 threads 275 k,
+// 128 threads 289 k, 256 threads 285 k frames/s (three runs each); one step at a time: 248 / 250 / 238 k.
+constexpr int kPyrThreads = ORBX_PYR_THREADS;
 constexpr int kResizeRows = 4;   // output rows per lane: taps are fetched once, source rows are reused
 
 typedef unsigned short us2v __attribute__((ext_vector_type(2)));
