@@ -82,12 +82,11 @@ struct OrbxErr {
 // neighbours, so a source row costs two permutes instead of eight byte extractions.  The taps come
 // as one int4 of source offsets and one uint4 of packed (a0 | a1 << 16) coefficients.
 // ======================================================================================
-#ifndef ORBX_PYR_THREADS
-#define ORBX_PYR_THREADS 128
-#endif
-// Threads per workgroup of the level-0 copy and the resize kernels.  Pipelined benchmark at 752x480: 64 threads 275 k,
-// 128 threads 289 k, 256 threads 285 k frames/s (three runs each); one step at a time: 248 / 250 / 238 k.
-constexpr int kPyrThreads = ORBX_PYR_THREADS;
+// Threads per workgroup of the level-0 copy and the resize kernels, chosen per image size.  Pipelined benchmark, three
+// runs each: 752x480 with 64 / 128 / 256 threads 275 / 288 / 283 k frames/s (one step at a time 248 / 252 / 237 k);
+// 1920x1080 with 128 / 256 threads 51.5 / 53.1 k.
+constexpr int kPyrThreadsMax = 256;
+static inline int pyr_threads_for(int w, int h) { return (long long)w * h <= (1ll << 20) ? 128 : 256; }
 constexpr int kResizeRows = 4;   // output rows per lane: taps are fetched once, source rows are reused
 
 typedef unsigned short us2v __attribute__((ext_vector_type(2)));
@@ -111,7 +110,7 @@ __device__ __forceinline__ void resize_hsum(const ResizeRaw r, int sh, const uin
                                       __builtin_bit_cast(us2v, co[i]), 0u, false) >> 4;
 }
 
-__global__ __launch_bounds__(kPyrThreads) void k_resize(const OrbxFrameGeo* __restrict__ geo, int level,
+__global__ __launch_bounds__(kPyrThreadsMax) void k_resize(const OrbxFrameGeo* __restrict__ geo, int level,
                                                 uint8_t* __restrict__ pyr, long long frameStride,
                                                 const int* __restrict__ xofs, const uint32_t* __restrict__ xcoef,
                                                 const int* __restrict__ yofs, const uint32_t* __restrict__ ycoef,
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(kPyrThreads) void k_resize(const OrbxFrameGeo* __re
 // 16 bytes per lane when the source is 16-byte aligned, bytes otherwise.  The first workgroup of every frame also
 // clears the frame's FAST candidate counters (the only per-batch state that must start at zero), which saves a
 // separate memset on the stream.
-__global__ __launch_bounds__(kPyrThreads) void k_copy_level0(const OrbxFrameGeo* __restrict__ geo,
+__global__ __launch_bounds__(kPyrThreadsMax) void k_copy_level0(const OrbxFrameGeo* __restrict__ geo,
                                                      const uint8_t* __restrict__ images, long long rowStride,
                                                      long long imgStride, uint8_t* __restrict__ pyr,
                                                      long long frameStride, int aligned16, int chunksPerRow,
@@ -2015,8 +2014,9 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
     for (int l = 1; l < nl; ++l) {
         const int lanes = (g.lv[l].w + 3) / 4;
         const int groups = (g.lv[l].h + kResizeRows - 1) / kResizeRows;
-        dim3 grid((unsigned)(((long long)lanes * groups + kPyrThreads - 1) / kPyrThreads), nf);
-        hipLaunchKernelGGL(k_resize, grid, dim3(kPyrThreads), 0, st, ex->d_geo, l, ex->d_pyr, g.pyrBytes, ex->d_xofs, ex->d_xcoef,
+        const int pyrThreads = pyr_threads_for(g.w, g.h);
+        dim3 grid((unsigned)(((long long)lanes * groups + pyrThreads - 1) / pyrThreads), nf);
+        hipLaunchKernelGGL(k_resize, grid, dim3(pyrThreads), 0, st, ex->d_geo, l, ex->d_pyr, g.pyrBytes, ex->d_xofs, ex->d_xcoef,
                            ex->d_yofs, ex->d_ycoef, lanes, lanes == 1 ? 0xFFFFFFFFu : (uint32_t)(0x100000000ull / (unsigned)lanes));
     }
     mark(ex, st);
@@ -2077,10 +2077,11 @@ extern "C" orbx_status orbx_extract_batch_device(orbx_extractor* ex, const uint8
     if (s != ORBX_OK) return s;
     hipStream_t st = (hipStream_t)stream;   // taken literally: NULL is the device's default stream
     const int chunksPerRow = (width + 15) / 16;
-    dim3 grid((unsigned)(((long long)chunksPerRow * height + kPyrThreads - 1) / kPyrThreads), n_frames);
+    const int pyrThreads = pyr_threads_for(width, height);
+    dim3 grid((unsigned)(((long long)chunksPerRow * height + pyrThreads - 1) / pyrThreads), n_frames);
     const int aligned16 = ((((uintptr_t)d_images) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
     mark(ex, st);
-    hipLaunchKernelGGL(k_copy_level0, grid, dim3(kPyrThreads), 0, st, ex->d_geo, d_images, (long long)row_stride,
+    hipLaunchKernelGGL(k_copy_level0, grid, dim3(pyrThreads), 0, st, ex->d_geo, d_images, (long long)row_stride,
                        (long long)frame_stride, ex->d_pyr, ex->geo.pyrBytes, aligned16, chunksPerRow, ex->d_candCount);
     return enqueue_batch(ex, n_frames, lap0, lap1, dyn_host, ndyn, d_keypoints, d_descriptors, capacity, d_counts, st, true);
 }
