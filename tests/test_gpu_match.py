@@ -246,6 +246,64 @@ def test_stereo_batch_device(oracle):
         assert np.array_equal(u[f, :n], uR) and np.array_equal(d[f, :n], depth)
 
 
+def test_pipelined_handle_sets_equal_sequential_results(oracle):
+    # The throughput pattern of the integration notes: consecutive batches alternate between two sets of (left handle,
+    # right handle, result arrays, stream pair) with no synchronisation in between; a set's next extraction only follows
+    # that set's previous stereo match in stream order.  Every batch must come out as if it had been run alone.
+    A = _gpu()
+    import torch
+    dev = torch.device("cuda", 0)
+    nb, nsteps = 3, 6
+    batches = []
+    for st in range(nsteps):
+        pairs = [synth.stereo_pair(752, 480, 300 + 10 * st + i) for i in range(nb)]
+        batches.append((torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev),
+                        torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)))
+    sets = []
+    for k in range(2):
+        eL = A.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=nb)
+        eR = A.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=nb)
+        sets.append(dict(eL=eL, eR=eR, a=torch.cuda.Stream(dev), b=torch.cuda.Stream(dev)))
+    cap = sets[0]["eL"].max_keypoints
+    mk = lambda: (torch.empty((nb, cap, 28), dtype=torch.uint8, device=dev),
+                  torch.empty((nb, cap, 32), dtype=torch.uint8, device=dev),
+                  torch.empty((nb, 2), dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+    results = []
+    for st in range(nsteps):
+        S = sets[st % 2]
+        oL, oR = mk(), mk()          # fresh result arrays per step so that every step can be checked afterwards
+        S["b"].wait_stream(S["a"])
+        with torch.cuda.stream(S["a"]):
+            S["eL"].extract_batch_device(batches[st][0], (0, 0), out=oL)
+        with torch.cuda.stream(S["b"]):
+            S["eR"].extract_batch_device(batches[st][1], (0, 0), out=oR)
+        S["a"].wait_stream(S["b"])
+        with torch.cuda.stream(S["a"]):
+            u, d = A.compute_stereo_matches_device(S["eL"], S["eR"], oL, oR, MBF, MBF / FX)
+            # the stereo matcher's outputs belong to the handles: copy them out in stream order
+            results.append((oL, oR, u.clone(), d.clone()))
+    torch.cuda.synchronize()
+    for S in sets:
+        S["eL"].status(); S["eR"].status()
+    # the same batches one at a time on one more pair of handles
+    rL = A.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=nb)
+    rR = A.ORBextractor(1000, 1.2, 8, 20, 7, max_batch=nb)
+    for st in range(nsteps):
+        qL = rL.extract_batch_device(batches[st][0], (0, 0))
+        qR = rR.extract_batch_device(batches[st][1], (0, 0))
+        u, d = A.compute_stereo_matches_device(rL, rR, qL, qR, MBF, MBF / FX)
+        torch.cuda.synchronize()
+        oL, oR, pu, pd = results[st]
+        assert torch.equal(oL[2], qL[2]) and torch.equal(oR[2], qR[2]), f"counts of step {st}"
+        for f in range(nb):
+            n = int(qL[2][f, 0]); m = int(qR[2][f, 0])
+            assert n > 500 and m > 500
+            assert torch.equal(oL[0][f, :n], qL[0][f, :n]) and torch.equal(oL[1][f, :n], qL[1][f, :n]), f"left {st}/{f}"
+            assert torch.equal(oR[0][f, :m], qR[0][f, :m]) and torch.equal(oR[1][f, :m], qR[1][f, :m]), f"right {st}/{f}"
+            assert torch.equal(pu[f, :n], u[f, :n]) and torch.equal(pd[f, :n], d[f, :n]), f"stereo {st}/{f}"
+
+
 def test_stereo_no_matches_is_safe():
     # unrelated left / right images: the reference would read an empty vector; we return none
     A = _gpu()
