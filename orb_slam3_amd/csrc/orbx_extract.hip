@@ -840,7 +840,12 @@ constexpr int kQtThreadsMax = 512;
 __host__ __device__ constexpr int qt_reg_keys(int threads) { return 4096 / threads < 16 ? 4096 / threads : 16; }
 // Measured in the pipelined benchmark (two handle sets, four streams), frames/s with 128 / 256 / 512 threads:
 // 752x480 with 1000 features 284 k / 277 k / 274 k, 1920x1080 with 5000 features 46.5 k / 52.5 k / 53.3 k.
-static inline int qt_threads_for(int nfeatures) { return nfeatures <= 1500 ? 128 : (nfeatures <= 3000 ? 256 : 512); }
+// A call with a few frames leaves the chip mostly empty: nothing competes for wave slots and the large workgroup's
+// shorter critical path wins (a single 752x480 frame through the host entry point: 0.164 ms with 128 threads, 0.155 with 512).
+static inline int qt_threads_for(int nfeatures, int nframes) {
+    if (nframes <= 8) return 512;
+    return nfeatures <= 1500 ? 128 : (nfeatures <= 3000 ? 256 : 512);
+}
 
 struct QtBox { short ulx, uly, brx, bry; };
 
@@ -1793,11 +1798,10 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
         ORBX_HIP_TRY(hipDeviceGetAttribute(&ldsMax, hipDeviceAttributeMaxSharedMemoryPerBlock, ex->device));
         ORBX_REQUIRE((long long)qtLds + 2048 <= ldsMax, "quadtree needs %zu bytes of LDS, the device offers %d", qtLds, ldsMax);
         if (qtLds > 32 * 1024) {
-            const int qtThreads = qt_threads_for(P.nfeatures);
-            const void* fn = qtThreads == 128 ? reinterpret_cast<const void*>(k_quadtree<128>)
-                             : qtThreads == 256 ? reinterpret_cast<const void*>(k_quadtree<256>)
-                                                : reinterpret_cast<const void*>(k_quadtree<512>);
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qtLds);
+            hipError_t e = hipSuccess;
+            for (const void* fn : {reinterpret_cast<const void*>(k_quadtree<128>), reinterpret_cast<const void*>(k_quadtree<256>),
+                                   reinterpret_cast<const void*>(k_quadtree<512>)})
+                if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qtLds);
             if (e != hipSuccess) {
                 orbx_set_error("cannot raise the dynamic LDS limit of the quadtree kernel to %zu (device max %d): %s", qtLds,
                                ldsMax, hipGetErrorString(e));
@@ -2034,7 +2038,7 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
                            ex->d_rects, ndyn, ex->d_err, g.tileP, g.tileR, g.fastQueueOff, nl, cellMagic);
     mark(ex, st);
     const size_t qtLds = (size_t)g.maxNodeCap * 56 + kQtThreadsMax * sizeof(int);
-    switch (qt_threads_for(ex->prm.nfeatures)) {
+    switch (qt_threads_for(ex->prm.nfeatures, nf)) {
         case 128:
             hipLaunchKernelGGL(k_quadtree<128>, dim3(nl, nf), dim3(128), qtLds, st, ex->d_geo, ex->d_cands, ex->d_candCount,
                                ex->d_keyNode, ex->d_levelKps, ex->d_kpCount, ex->d_err);
