@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kPyrThreadsMax) void k_resize(const OrbxFrameGeo* _
         ResizeRaw raw0[kResizeRows], raw1[kResizeRows];
 #pragma unroll
         for (int r = 0; r < kResizeRows; ++r) {
-            raw0[r] = raw1[r] = ResizeRaw{0u, 0u, 0u};
+            // (a row's window is only read when it was requested: no initialisation)
             if (need0[r]) raw0[r] = resize_load(src + (long long)sy0[r] * S.pitch, base);
             if (need1[r]) raw1[r] = resize_load(src + (long long)sy1[r] * S.pitch, base);
         }
