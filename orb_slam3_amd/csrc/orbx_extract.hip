@@ -1727,15 +1727,20 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
         L.w = round_half_even_f((float)w * ex->inv_sf[l]);
         L.h = round_half_even_f((float)h * ex->inv_sf[l]);
         const float width = (float)(L.w - 2 * kOrbxMinBorder), height = (float)(L.h - 2 * kOrbxMinBorder);
-        ORBX_REQUIRE(width >= 35.f && height >= 35.f,
-                     "level %d of a %dx%d image is %dx%d: too small for the 35-px FAST grid", l, w, h, L.w, L.h);
+        // A level narrower or lower than one 35-px cell has no cells (ORBextractor.cc:914-915: nCols or nRows is 0
+        // and the cell loops do not run): it yields no keypoints and its quota is lost, but it is still the source
+        // of the next level.  Level 0 must have a cell, or there is nothing to launch.
+        const bool hasCells = width >= 35.f && height >= 35.f;
+        ORBX_REQUIRE(hasCells || l > 0,
+                     "a %dx%d image is too small for the 35-px FAST grid", w, h);
+        ORBX_REQUIRE(L.w >= 8 && L.h >= 8, "level %d of a %dx%d image is %dx%d: fewer than 8 pixels a side", l, w, h, L.w, L.h);
         ORBX_REQUIRE(L.w < 32000 && L.h < 32000, "image too large");
         L.pitch = (L.w + 63) & ~63;
         L.off = off;
         off += (long long)L.pitch * L.h;
         off = (off + 255) & ~255ll;
-        L.nCols = (int)(width / 35.f); L.nRows = (int)(height / 35.f);
-        L.wCell = (int)std::ceil(width / L.nCols); L.hCell = (int)std::ceil(height / L.nRows);
+        L.nCols = hasCells ? (int)(width / 35.f) : 0; L.nRows = hasCells ? (int)(height / 35.f) : 0;
+        L.wCell = hasCells ? (int)std::ceil(width / L.nCols) : 0; L.hCell = hasCells ? (int)std::ceil(height / L.nRows) : 0;
         const int maxBX = L.w - kOrbxMinBorder, maxBY = L.h - kOrbxMinBorder;
         L.nColsP = 0; L.nRowsP = 0;
         for (int j = 0; j < L.nCols; ++j) if (!((float)(kOrbxMinBorder + j * L.wCell) >= (float)(maxBX - 3))) L.nColsP = j + 1;
@@ -1744,9 +1749,10 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
         L.cellBase = cellBase;
         cellBase += L.nColsP * L.nRowsP;
         L.quota = ex->quota[l];
-        L.nIni = (int)std::round((float)(maxBX - kOrbxMinBorder) / (maxBY - kOrbxMinBorder));
+        // (a level without cells has no keys to distribute: one root that stays empty)
+        L.nIni = hasCells ? (int)std::round((float)(maxBX - kOrbxMinBorder) / (maxBY - kOrbxMinBorder)) : 1;
         ORBX_REQUIRE(L.nIni >= 1, "level %d is taller than twice its width: the quadtree has no root", l);
-        L.hX = (float)(maxBX - kOrbxMinBorder) / L.nIni;
+        L.hX = hasCells ? (float)(maxBX - kOrbxMinBorder) / L.nIni : 1.f;
         long long px = (long long)L.w * L.h;
         L.candCap = (int)std::min<long long>(std::max<long long>(px >> ex->candShift, 2048), (px + 3) / 4 + 16);
         L.candOff = candOff;
@@ -1782,6 +1788,7 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
         for (int l = 0; l < P.nlevels; ++l)
             for (int ox = 0; ox < 4; ++ox) {
                 const int iw = g.lv[l].wCell, ih = g.lv[l].hCell;
+                if (iw == 0) continue;     // a level without cells
                 const int ncol = ((ox + 3 + iw - 1) >> 2) - ((ox + 3) >> 2) + 1;
                 const int rows1 = fast_band_rows(ncol, ih, 64);
                 maxBandRows = std::max(maxBandRows, rows1 > 8 ? fast_band_rows(ncol, ih, 128) : rows1);

@@ -119,6 +119,37 @@ def test_scale_factor_and_levels_variants(oracle):
         _same(*o(img, (0, 0)), *g(img, (0, 0)))
 
 
+def test_random_geometries(oracle):
+    # Sizes, pyramid shapes, quotas and thresholds drawn at random: the cell grid, the tile pitch, the rows a FAST
+    # wave takes and the alignment of every level row all depend on them.
+    A = _gpu()
+    rng = np.random.default_rng(20240607)
+    for case in range(24):
+        w = int(rng.integers(120, 1300))
+        h = int(rng.integers(100, min(800, w * 6 // 5) + 1))    # (a level much taller than wide has no quadtree root: refused)
+        sf = float(rng.choice([1.1, 1.2, 1.25, 1.33, 1.5, 2.0]))
+        nl = int(rng.integers(1, 9))
+        while nl > 1 and min(w, h) / sf ** (nl - 1) < 12:      # levels without room for a FAST cell are wanted, levels of a few pixels are not
+            nl -= 1
+        nf = int(rng.integers(60, 3000))
+        if nl == 1:
+            nf = min(nf, 2500)                                  # one level takes the whole quota: the on-chip quadtree holds 2800 nodes
+        ini = int(rng.integers(4, 40))
+        mn = int(rng.integers(1, ini + 1))
+        lap = (0, 0) if case % 3 else (int(rng.integers(0, w // 2)), int(rng.integers(w // 2, w)))
+        img = synth.scene(w, h, 100 + case, n_prims=int(rng.integers(20, 200)), noise_sigma=float(rng.uniform(0, 3)))
+        o = oracle.Extractor(nf, sf, nl, ini, mn)
+        g = A.ORBextractor(nf, sf, nl, ini, mn, max_width=w, max_height=h)
+        try:
+            ko, do, mo = o(img, lap)
+            kg, dg, mg = g(img, lap)
+            _same(ko, do, mo, kg, dg, mg)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: {w}x{h} sf={sf} nl={nl} nf={nf} th=({ini},{mn}) lap={lap}: {e}")
+        finally:
+            g.close()
+
+
 def test_dynamic_rects(oracle):
     A = _gpu()
     img = synth.scene(640, 480, 5)
@@ -153,7 +184,12 @@ def test_empty_and_invalid(oracle):
     with pytest.raises(A.OrbxError):
         g(np.zeros((1000, 1000), np.uint8))       # larger than the handle
     with pytest.raises(A.OrbxError):
-        g(np.zeros((100, 100), np.uint8))         # top level too small for the 35-px grid
+        g(np.zeros((60, 60), np.uint8))           # level 0 has no room for one 35-px cell
+    with pytest.raises(A.OrbxError):
+        g(np.zeros((480, 200), np.uint8))         # more than twice as tall as wide: DistributeOctTree would have no root node
+    # upper levels without room for a cell are not an error: they contribute nothing (ORBextractor.cc:914-915)
+    small = synth.scene(100, 100, 3)
+    _same(*oracle.Extractor(500, 1.2, 8, 20, 7)(small, (0, 0)), *g(small, (0, 0)))
     with pytest.raises(A.OrbxError):
         A.ORBextractor(500, 1.2, 40, 20, 7)
 
