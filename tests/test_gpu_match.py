@@ -174,6 +174,51 @@ def test_stereo_match_matches_oracle(oracle, seed):
     assert np.array_equal(d, depth)
 
 
+def _random_stereo_cases():
+    rng = np.random.default_rng(424242)
+    for case in range(10):
+        w = int(rng.integers(320, 1300))
+        h = int(rng.integers(200, min(800, w * 6 // 5) + 1))
+        sf = float(rng.choice([1.1, 1.2, 1.5]))
+        nl = int(rng.integers(2, 9))
+        while nl > 1 and min(w, h) / sf ** (nl - 1) < 12:
+            nl -= 1
+        nf = int(rng.integers(300, 2500))
+        mbf, fx = float(rng.uniform(20, 500)), float(rng.uniform(300, 800))
+        yield case, w, h, sf, nl, nf, mbf, fx
+
+
+def test_stereo_random_geometries(oracle):
+    # Frame sizes, pyramid shapes, quotas and calibrations drawn at random: row bands, the disparity range
+    # (minD = 0, maxD = mbf / b with b = mbf / fx) and the 11 x 11 SAD windows near the level borders all depend on them.
+    A = _gpu()
+    matched = 0
+    for case, w, h, sf, nl, nf, mbf, fx in _random_stereo_cases():
+        L, R = synth.stereo_pair(w, h, 300 + case)
+        eL, eR = oracle.Extractor(nf, sf, nl, 20, 7), oracle.Extractor(nf, sf, nl, 20, 7)
+        kL, dL, _ = eL(L, (0, 0))
+        kR, dR, _ = eR(R, (0, 0))
+        pl = [eL.pyramid_level(l) for l in range(nl)]
+        pr = [eR.pyramid_level(l) for l in range(nl)]
+        uR, depth, _, _ = oracle.stereo_match(kL, dL, kR, dR, pl, pr, eL.scale_factors, eL.inv_scale_factors, mbf, mbf / fx)
+        gl = A.ORBextractor(nf, sf, nl, 20, 7, w, h)
+        gr = A.ORBextractor(nf, sf, nl, 20, 7, w, h)
+        try:
+            kgl, dgl, _ = gl(L, (0, 0))
+            kgr, dgr, _ = gr(R, (0, 0))
+            assert np.array_equal(kgl, kL) and np.array_equal(kgr, kR), "keypoints"
+            u, d = A.compute_stereo_matches(gl, gr, kgl, dgl, kgr, dgr, mbf, mbf / fx)
+            assert np.array_equal(u, uR), "uRight"
+            assert np.array_equal(d, depth), "depth"
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: {w}x{h} sf={sf} nl={nl} nf={nf} mbf={mbf} fx={fx}: {e}")
+        finally:
+            gl.close()
+            gr.close()
+        matched += int((uR >= 0).sum())
+    assert matched > 500
+
+
 def test_kitti_style_stereo_and_tumvi_fisheye_knn(oracle):
     """The other two stereo configurations of the metric: 1241 x 376 with 2000 features through the row-band
     search, and 512 x 512 fisheye
