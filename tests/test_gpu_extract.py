@@ -150,6 +150,47 @@ def test_random_geometries(oracle):
             g.close()
 
 
+def test_random_batches_with_rects(oracle):
+    # The device-resident batch path at random geometries, with erase rectangles and a lapping area: every frame
+    # of the batch against the oracle.
+    A = _gpu()
+    import torch
+    rng = np.random.default_rng(77001)
+    for case in range(8):
+        w = int(rng.integers(200, 1000))
+        h = int(rng.integers(150, min(700, w * 6 // 5) + 1))
+        sf = float(rng.choice([1.2, 1.25, 1.5]))
+        nl = int(rng.integers(2, 9))
+        while nl > 1 and min(w, h) / sf ** (nl - 1) < 12:
+            nl -= 1
+        nf = int(rng.integers(100, 2000))
+        nb = int(rng.integers(2, 6))
+        lap = (int(rng.integers(0, w // 2)), int(rng.integers(w // 2, w))) if case % 2 else (0, 0)
+        rects = []
+        for _ in range(int(rng.integers(0, 4))):
+            rx, ry = int(rng.integers(0, w - 40)), int(rng.integers(0, h - 40))
+            rects.append((rx, ry, int(rng.integers(10, w - rx)), int(rng.integers(10, h - ry))))
+        imgs = [synth.scene(w, h, 500 + 10 * case + i, n_prims=int(rng.integers(30, 200))) for i in range(nb)]
+        o = oracle.Extractor(nf, sf, nl, 20, 7)
+        g = A.ORBextractor(nf, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=nb)
+        g.mvDynamicArea = rects
+        try:
+            kps, desc, counts = g.extract_batch_device(torch.from_numpy(np.stack(imgs)).cuda(), lap)
+            torch.cuda.synchronize()
+            g.status()
+            kps, desc, counts = kps.cpu().numpy(), desc.cpu().numpy(), counts.cpu().numpy()
+            for f in range(nb):
+                ko, do, mo = o(imgs[f], lap, rects)
+                n = int(counts[f, 0])
+                assert n == len(ko) and int(counts[f, 1]) == mo, f"frame {f}: counts"
+                assert np.array_equal(np.frombuffer(kps[f, :n].tobytes(), dtype=A.KP_DTYPE), ko), f"frame {f}: keypoints"
+                assert np.array_equal(desc[f, :n], do), f"frame {f}: descriptors"
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: {nb} x {w}x{h} sf={sf} nl={nl} nf={nf} lap={lap} rects={rects}: {e}")
+        finally:
+            g.close()
+
+
 def test_dynamic_rects(oracle):
     A = _gpu()
     img = synth.scene(640, 480, 5)
