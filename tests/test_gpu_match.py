@@ -48,6 +48,37 @@ def test_knn2_matches_oracle(oracle, nq, nt):
     assert np.array_equal(_m2(A.knn_match2(q, t)), oracle.knn2(q, t))
 
 
+def test_knn2_random_sizes(oracle):
+    # Query and map counts around the tile edges of the search kernel, plain and low-entropy (many exact ties),
+    # with a shard offset: best / second best (distance, then lower index) against the oracle.
+    A = _gpu()
+    import torch
+    rng = np.random.default_rng(909)
+    spans_q = [(1, 70), (120, 140), (250, 260), (1000, 1100)]
+    spans_t = [(1, 130), (250, 260), (1000, 1100), (16380, 16390), (30000, 70000)]
+    for case in range(16):
+        a, b = spans_q[int(rng.integers(0, len(spans_q)))]
+        nq = int(rng.integers(a, b + 1))
+        a, b = spans_t[int(rng.integers(0, len(spans_t)))]
+        nt = int(rng.integers(a, b + 1))
+        if case % 4 == 3:      # few distinct values: ties everywhere
+            q = np.zeros((nq, 32), np.uint8); q[:, :2] = rng.integers(0, 4, (nq, 2))
+            t = np.zeros((nt, 32), np.uint8); t[:, :2] = rng.integers(0, 4, (nt, 2))
+        else:
+            q = synth.random_descriptors(nq, 1000 + case)
+            t, _ = synth.planted_map(q, nt, 2000 + case)
+        ref = oracle.knn2(q, t)
+        assert np.array_equal(_m2(A.knn_match2(q, t)), ref), f"case {case}: {nq} x {nt}"
+        base = int(rng.integers(0, 1 << 20))
+        r, _ = A.knn_match2_device(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda(), base_index=base)
+        torch.cuda.synchronize()
+        r = r.cpu().numpy()
+        exp = ref.copy()
+        exp[:, 0] = np.where(ref[:, 0] >= 0, ref[:, 0] + base, ref[:, 0])
+        exp[:, 2] = np.where(ref[:, 2] >= 0, ref[:, 2] + base, ref[:, 2])
+        assert np.array_equal(r, exp), f"case {case}: {nq} x {nt} at base {base}"
+
+
 def test_knn2_golden(golden_dir):
     A = _gpu()
     g = np.load(os.path.join(golden_dir, "knn2_planted.npz"))
