@@ -191,6 +191,49 @@ def test_random_batches_with_rects(oracle):
             g.close()
 
 
+def _pattern_images(w, h):
+    """Image kinds that synth.scene does not make: periodic patterns (equal FAST scores everywhere: ties in the
+    3x3 suppression, in the quadtree's response sort and in its final choice), dense noise (every cell full) and
+    blocky noise (corners on a lattice)."""
+    rng = np.random.default_rng(w * 1000 + h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = {}
+    for period in (4, 7, 16):
+        out[f"checkerboard {period}"] = ((((xx // period) + (yy // period)) & 1) * 200 + 20).astype(np.uint8)
+    out["stripes"] = (((xx // 5) & 1) * 180 + ((yy // 9) & 1) * 60).astype(np.uint8)
+    out["dots"] = np.where((xx % 11 == 5) & (yy % 13 == 6), 255, 30).astype(np.uint8)
+    out["uniform noise"] = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    blocks = rng.integers(0, 256, ((h + 5) // 6, (w + 5) // 6), dtype=np.uint8)
+    out["blocky noise"] = np.kron(blocks, np.ones((6, 6), np.uint8))[:h, :w].copy()
+    out["two values"] = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
+    ramp = (xx * 255 // (w - 1)).astype(np.uint8)
+    out["ramp + sparse dots"] = np.where(rng.random((h, w)) < 0.002, 255 - ramp, ramp).astype(np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("w,h,nf", [(640, 480, 1000), (453, 331, 2500), (1920, 1080, 5000)])
+def test_periodic_and_noise_images(oracle, w, h, nf):
+    A = _gpu()
+    o = oracle.Extractor(nf, 1.2, 8, 20, 7)
+    g = A.ORBextractor(nf, 1.2, 8, 20, 7, max_width=w, max_height=h)
+    total = 0
+    for name, img in _pattern_images(w, h).items():
+        ko, do, mo = o(img, (0, 0))
+        try:
+            kg, dg, mg = g(img, (0, 0))
+        except A.OrbxError as e:
+            if e.status != -2:
+                raise
+            kg, dg, mg = g(img, (0, 0))      # the candidate buffers were regrown: the second call fits
+        try:
+            _same(ko, do, mo, kg, dg, mg)
+        except AssertionError as e:
+            raise AssertionError(f"{name} {w}x{h}: {e}")
+        total += len(ko)
+    assert total > 5 * nf
+    g.close()
+
+
 def test_dynamic_rects(oracle):
     A = _gpu()
     img = synth.scene(640, 480, 5)
