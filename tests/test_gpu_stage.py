@@ -40,6 +40,30 @@ def test_stage_equals_oracle(oracle, cn, rgb, mode):
     assert np.array_equal(got, want)
 
 
+def test_stage_random_geometries(oracle):
+    # Source and destination sizes, channel layouts and modes drawn at random (the scale factors of the resize and
+    # the ragged ends of source and destination rows all depend on them).
+    A = _gpu()
+    rng = np.random.default_rng(515)
+    for case in range(24):
+        w, h = int(rng.integers(17, 700)), int(rng.integers(9, 500))
+        cn = int(rng.choice([1, 3, 4]))
+        rgb = bool(rng.integers(0, 2)) if cn > 1 else False
+        mode = ["none", "remap", "remap_other_size", "resize"][int(rng.integers(0, 4))]
+        img = synth.scene(w, h, 600 + case, n_prims=40) if cn == 1 else synth.color_scene(w, h, 600 + case, cn)
+        kw = {}
+        if mode == "remap":
+            kw["maps"] = synth.rectify_maps(w, h, 700 + case, strength=float(rng.uniform(0.05, 0.6)))
+        elif mode == "remap_other_size":
+            kw["maps"] = synth.rectify_maps(w, h, 700 + case, (int(rng.integers(8, 800)), int(rng.integers(8, 600))))
+        elif mode == "resize":
+            kw["size"] = (int(rng.integers(8, 900)), int(rng.integers(8, 700)))
+        st = A.InputStager(w, h, cn, rgb, **kw)
+        got = st(img)
+        want = oracle.stage(img, rgb=rgb, **kw)
+        assert got.shape == want.shape and np.array_equal(got, want), f"case {case}: {w}x{h}x{cn} rgb={rgb} {mode} {kw.get('size')}"
+
+
 def test_stage_maps_far_outside_and_fraction_rounding(oracle):
     A = _gpu()
     rng = np.random.default_rng(3)
