@@ -103,3 +103,33 @@ def test_distinctive_descriptors(oracle):
     bi, bm = A.distinctive_descriptors(desc, off)
     assert np.array_equal(bi, bi_o) and np.array_equal(bm, bm_o)
     assert bi[0] == -1 and bi[1] == 0 and bm[1] == 0
+
+
+def test_bow_and_distinctive_random_shapes(oracle):
+    """Vocabulary shapes (branching factor, depth, pruned subtrees), feature counts and levelsup drawn at random;
+    random observation-count profiles for the distinctive-descriptor choice."""
+    A = _gpu()
+    rng = np.random.default_rng(616)
+    for case in range(10):
+        k = int(rng.choice([2, 3, 5, 9, 10, 17, 64, 65, 100]))
+        depth = int(rng.integers(1, 9))
+        while k ** depth > 40000:
+            depth -= 1
+        prune = float(rng.choice([0.0, 0.1, 0.3]))
+        levelsup = int(rng.integers(0, depth + 2))
+        n = int(rng.integers(1, 3000))
+        voc = synth.vocabulary(k, depth, 40 + case, prune)
+        desc = _features(voc, n, 140 + case)
+        wo, we, no = oracle.bow_transform(*voc[:5], voc[5], desc, levelsup)
+        wg, weg, ng = A.Vocabulary(*voc).transform_features(desc, levelsup)
+        assert np.array_equal(wg, wo) and np.array_equal(weg, we) and np.array_equal(ng, no), \
+            f"case {case}: k={k} depth={depth} prune={prune} levelsup={levelsup} n={n}"
+    for case in range(4):
+        counts = list(rng.integers(0, [6, 40, 130, 385][case], 300))
+        off = np.zeros(len(counts) + 1, np.int32)
+        off[1:] = np.cumsum(counts)
+        desc = np.repeat(synth.random_descriptors(len(counts), 50 + case), counts, axis=0)
+        desc = synth.noisy_copy(rng, desc, [2, 10, 30, 60][case])      # few flips: many equal distances and tied medians
+        bi_o, bm_o = oracle.distinctive_descriptors(desc, off)
+        bi, bm = A.distinctive_descriptors(desc, off)
+        assert np.array_equal(bi, bi_o) and np.array_equal(bm, bm_o), f"distinctive case {case}"
