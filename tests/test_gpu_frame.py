@@ -226,3 +226,40 @@ def test_frame_from_distorted_keypoints(oracle, dist):
     un2, b2 = f2.keypoints()
     assert np.array_equal(un2, un) and np.array_equal(b2, b)
     assert all(np.array_equal(x, y) for x, y in zip(f2.grid(), (start, idx)))
+
+
+def test_random_cameras_and_keypoint_sets(oracle):
+    """Calibrations (focal lengths, principal points, 4 / 5 / 8 distortion coefficients of random size), image
+    sizes and keypoint counts drawn at random: undistorted coordinates, image bounds and grid against the oracle."""
+    A = _gpu()
+    rng = np.random.default_rng(717)
+    for case in range(16):
+        w, h = int(rng.integers(160, 2000)), int(rng.integers(120, 1300))
+        f = float(rng.uniform(0.4, 1.2)) * w
+        K = (f, f * float(rng.uniform(0.97, 1.03)), w * float(rng.uniform(0.45, 0.55)), h * float(rng.uniform(0.45, 0.55)))
+        nd = int(rng.choice([4, 5, 8]))
+        scale = np.array([0.3, 0.1, 2e-3, 2e-3, 0.05, 0.02, 0.02, 0.01])[:nd]
+        dist = tuple(float(v) for v in rng.normal(0, 1, nd) * scale * float(rng.uniform(0.1, 1.0)))
+        n = int(rng.integers(0, 6000)) if case % 4 else int(rng.integers(0, 20))
+        kps = np.zeros(n, A.KP_DTYPE)
+        kps["x"] = rng.uniform(0, w - 1, n).astype(np.float32)
+        kps["y"] = rng.uniform(0, h - 1, n).astype(np.float32)
+        kps["octave"] = rng.integers(0, 8, n)
+        kps["angle"] = rng.uniform(0, 360, n).astype(np.float32)
+        desc = synth.random_descriptors(n, 800 + case)
+        cam = A.Camera(*K, dist)
+        what = f"case {case}: {w}x{h}, K={K}, dist={dist}, {n} keypoints"
+        want_b = oracle.image_bounds(w, h, K, dist)
+        assert np.array_equal(cam.image_bounds(w, h), want_b), what
+        xy = np.stack([kps["x"], kps["y"]], 1)
+        want_xy = oracle.undistort_points(xy, K, dist) if dist[0] != 0 and n else xy
+        fr = A.FrameFeatures().assign_distorted(cam, w, h, kps, desc)
+        un, b = fr.keypoints()
+        assert np.array_equal(b, want_b), what
+        assert np.array_equal(np.stack([un["x"], un["y"]], 1), want_xy), what
+        want_un = kps.copy()
+        if n:
+            want_un["x"], want_un["y"] = want_xy[:, 0], want_xy[:, 1]
+        start_o, idx_o = oracle.Grid(want_un, *map(float, want_b)).csr()
+        start, idx = fr.grid()
+        assert np.array_equal(start, start_o) and np.array_equal(idx, idx_o), what
