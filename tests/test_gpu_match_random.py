@@ -1,6 +1,8 @@
 """Seed sweeps of the order-dependent ORBmatcher loops: list sizes, query counts, vocabulary node counts, noise
 levels and gates drawn at random, every case against the CPU oracle's restatement of the reference loop.
 Bar: identical match arrays and identical return values."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,6 +12,10 @@ from orb_slam3_amd import synth
 
 BOUNDS = (0.0, 752.0, 0.0, 480.0)
 SF = np.array([1.2 ** i for i in range(8)], np.float32)
+
+
+# ORBX_SWEEP=n adds n more seeds to every sweep (a hunt run by hand; the default set runs with the suite)
+_EXTRA = int(os.environ.get("ORBX_SWEEP", "0"))
 
 
 def _gpu():
@@ -22,7 +28,7 @@ def _fail(name, seed, detail, e):
     raise AssertionError(f"{name} seed {seed} ({detail}): {e}")
 
 
-@pytest.mark.parametrize("seed", range(201, 209))
+@pytest.mark.parametrize("seed", range(201, 209 + _EXTRA))
 def test_window_searches(oracle, seed):
     """SearchByProjection-style best(/second) searches with the "taken" rule (ORBmatcher.cc:42, :476, :582, :1761,
     :1974) and Fuse (:1214)."""
@@ -69,7 +75,7 @@ def test_window_searches(oracle, seed):
         _fail("window", seed, detail, e)
 
 
-@pytest.mark.parametrize("seed", range(301, 307))
+@pytest.mark.parametrize("seed", range(301, 307 + _EXTRA))
 def test_initialization_and_bow(oracle, seed):
     """SearchForInitialization (ORBmatcher.cc:695), SearchByBoW for a frame (:235) and for two keyframes (:824)."""
     A = _gpu()
@@ -119,7 +125,7 @@ def test_initialization_and_bow(oracle, seed):
         _fail("initialization / bow", seed, detail, e)
 
 
-@pytest.mark.parametrize("seed", range(401, 407))
+@pytest.mark.parametrize("seed", range(401, 407 + _EXTRA))
 def test_triangulation(oracle, seed):
     """SearchForTriangulation (ORBmatcher.cc:968): per shared node all pairs, epipole and epipolar gates."""
     A = _gpu()
