@@ -161,17 +161,22 @@ class Extractor:
         assert image.dtype == np.uint8 and image.ndim == 2
         h, w = image.shape
         cap = self.nfeatures + 16 * self.nlevels + 64
-        kps = np.zeros(cap, KP_DTYPE)
-        desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int()
         rects = None
         nr = 0
         if dynamic_rects is not None and len(dynamic_rects):
             rects = np.ascontiguousarray(dynamic_rects, np.int32).reshape(-1, 4)
             nr = len(rects)
-        mono = self.L.orc_extract(self.h, image.ctypes.data, w, h, image.strides[0], int(lapping[0]),
-                                  int(lapping[1]), _p(rects), nr, _p(kps), _p(desc), cap, C.byref(n))
-        assert n.value <= cap
+        while True:
+            kps = np.zeros(cap, KP_DTYPE)
+            desc = np.zeros((cap, 32), np.uint8)
+            mono = self.L.orc_extract(self.h, image.ctypes.data, w, h, image.strides[0], int(lapping[0]),
+                                      int(lapping[1]), _p(rects), nr, _p(kps), _p(desc), cap, C.byref(n))
+            if n.value <= cap:
+                break
+            # a level whose quota is below its number of quadtree roots keeps one keypoint per non-empty root
+            # (ORBextractor.cc:665-700): far more than nfeatures for a tiny quota on a wide image
+            cap = n.value
         return kps[:n.value].copy(), desc[:n.value].copy(), mono
 
     def pyramid_level(self, level):

@@ -1,6 +1,9 @@
 """Random-case hunt for extraction differences between the HIP path and the CPU oracle (not collected by pytest).
 
-    python tests/fuzz_extract.py [n_cases] [seed]
+    python tests/fuzz_extract.py [n_cases] [seed] [batch]
+
+With a third argument the device-resident batch entry point is used instead of the one-image host entry point:
+1..8 frames per call in a device tensor whose rows and frames are padded by random amounts.
 
 Draws image size, pyramid shape, quota, thresholds, lapping area, erase rectangles and image kind at random, runs both
 sides and prints every case that differs (with the parameters needed to replay it).  Exit status 1 if any differ."""
@@ -56,9 +59,36 @@ def image(p):
     return img
 
 
+def run_batch(g, p, imgs, rng):
+    """The frames through extract_batch_device from a padded device tensor; returns a list of (kps, desc, mono)."""
+    import torch
+    nb, h, w = len(imgs), p["h"], p["w"]
+    row = w + int(rng.integers(0, 70))
+    rows = h + int(rng.integers(0, 5))
+    buf = torch.zeros((nb, rows, row), dtype=torch.uint8, device="cuda")
+    buf[:, :h, :w] = torch.from_numpy(np.stack(imgs)).cuda()
+    view = buf[:, :h, :w]
+    for attempt in range(2):
+        kps, desc, counts = g.extract_batch_device(view, p["lap"])
+        torch.cuda.synchronize()
+        try:
+            g.status()
+            break
+        except A.OrbxError as e:
+            if e.status != -2 or attempt:
+                raise
+    kps, desc, counts = kps.cpu().numpy(), desc.cpu().numpy(), counts.cpu().numpy()
+    out = []
+    for f in range(nb):
+        m = int(counts[f, 0])
+        out.append((np.frombuffer(kps[f, :m].tobytes(), dtype=A.KP_DTYPE), desc[f, :m], int(counts[f, 1])))
+    return out
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    batch = len(sys.argv) > 3
     O.build()
     O.lib()
     rng = np.random.default_rng(seed)
@@ -68,13 +98,39 @@ def main():
         p = draw(rng, case)
         img = image(p)
         o = O.Extractor(p["nf"], p["sf"], p["nl"], p["ini"], p["mn"])
-        ko, do, mo = o(img, p["lap"], p["rects"])
+        nb = int(rng.integers(1, 9)) if batch else 1
         try:
-            g = A.ORBextractor(p["nf"], p["sf"], p["nl"], p["ini"], p["mn"], max_width=p["w"], max_height=p["h"])
+            g = A.ORBextractor(p["nf"], p["sf"], p["nl"], p["ini"], p["mn"], max_width=p["w"], max_height=p["h"], max_batch=nb)
         except A.OrbxError as e:
             print(f"refused {p}: {e}", flush=True)
             continue
         g.mvDynamicArea = p["rects"]
+        if batch:
+            imgs = [img]
+            for f in range(1, nb):
+                q = dict(p)
+                q["img_seed"] = p["img_seed"] + f
+                imgs.append(image(q))
+            try:
+                got = run_batch(g, p, imgs, rng)
+                same = True
+                for f in range(nb):
+                    ko, do, mo = o(imgs[f], p["lap"], p["rects"])
+                    kg, dg, mg = got[f]
+                    same = same and mo == mg and len(ko) == len(kg) and np.array_equal(do, dg) and all(
+                        np.array_equal(ko[x], kg[x]) for x in ("x", "y", "size", "angle", "response", "octave", "class_id"))
+            except A.OrbxError as e:
+                print(f"error {p}: {e}", flush=True)
+                same = False
+            finally:
+                g.close()
+            if not same:
+                bad += 1
+                print(f"DIFFERENT (batch of {nb}) {p}", flush=True)
+            if case % 10 == 9:
+                print(f"{case + 1} cases, {bad} different, {time.time() - t0:.0f} s", flush=True)
+            continue
+        ko, do, mo = o(img, p["lap"], p["rects"])
         try:
             try:
                 kg, dg, mg = g(img, p["lap"])
