@@ -97,8 +97,11 @@ orbx_status orbx_extractor_tables(const orbx_extractor* ex, float* scale, float*
 orbx_status orbx_scale_tables(int nfeatures, float scale_factor, int nlevels, float* scale, float* inv_scale,
                               float* sigma2, float* inv_sigma2, int* features_per_level);
 
-/* Largest number of keypoints one frame can yield (>= nfeatures); size output buffers
- * with it. */
+/* Largest number of keypoints one frame of the current image size can yield (>= nfeatures; at creation the
+ * size is max_width x max_height); size output buffers with it.  DistributeOctTree keeps one keypoint per
+ * non-empty root node even when a level's quota is smaller (ORBextractor.cc:665-700), and a wider aspect ratio has
+ * more roots: after a call with another size the value may be larger, and a call whose `capacity` was too small
+ * returns ORBX_ERR_CAPACITY; ask again and repeat the call with larger buffers. */
 int orbx_extractor_max_keypoints(const orbx_extractor* ex);
 
 /* ORBextractor::operator() (ORBextractor.cc:1271-1399) for one host image.

@@ -1628,6 +1628,7 @@ struct orbx_extractor {
     uint8_t* d_outDesc = nullptr;
     int* d_counts = nullptr;
     int outCap = 0;
+    int stageOutCap = 0;           // outCap the pinned result arrays were allocated for
     int lastFrames = 0;
     void* d_scratch = nullptr;     size_t scratchAlloc = 0;
     // pinned / device staging of the host entry points
@@ -2159,7 +2160,7 @@ extern "C" orbx_status orbx_extract_status(orbx_extractor* ex) {
 static orbx_status ensure_host_staging(orbx_extractor* ex) {
     const size_t inBytes = (size_t)ex->prm.max_batch * ex->prm.max_width * ex->prm.max_height;
     const size_t B = (size_t)ex->prm.max_batch;
-    if (ex->h_in && ex->stageInBytes >= inBytes) return ORBX_OK;
+    if (ex->h_in && ex->stageInBytes >= inBytes && ex->stageOutCap >= ex->outCap) return ORBX_OK;
     if (ex->h_in) { hipHostFree(ex->h_in); ex->h_in = nullptr; }
     if (ex->d_in) { hipFree(ex->d_in); ex->d_in = nullptr; }
     if (ex->h_outKps) { hipHostFree(ex->h_outKps); ex->h_outKps = nullptr; }
@@ -2171,6 +2172,7 @@ static orbx_status ensure_host_staging(orbx_extractor* ex) {
     ORBX_HIP_TRY(hipHostMalloc((void**)&ex->h_outDesc, B * ex->outCap * 32));
     ORBX_HIP_TRY(hipHostMalloc((void**)&ex->h_counts, B * 2 * sizeof(int)));
     ex->stageInBytes = inBytes;
+    ex->stageOutCap = ex->outCap;
     ++ex->geoEpoch;
     return ORBX_OK;
 }
@@ -2182,6 +2184,20 @@ static orbx_status extract_host(orbx_extractor* ex, const uint8_t* const* images
     ORBX_HIP_TRY(hipSetDevice(ex->device));
     orbx_status s = ensure_geometry(ex, width, height);
     if (s != ORBX_OK) return s;
+    if (ex->geo.kpTotal > ex->outCap) {
+        // A size whose levels can hold more keypoints than those of the size the handle was created for (a wider
+        // aspect ratio has more quadtree roots per level): the result arrays grow with it.
+        ORBX_HIP_TRY(hipStreamSynchronize(ex->stream));
+        const size_t B = (size_t)ex->prm.max_batch;
+        const int want = ex->geo.kpTotal;
+        hipFree(ex->d_outKps); ex->d_outKps = nullptr;
+        hipFree(ex->d_outDesc); ex->d_outDesc = nullptr;
+        ex->outCap = 0;            // until both allocations have succeeded
+        ++ex->geoEpoch;
+        ORBX_HIP_TRY(hipMalloc((void**)&ex->d_outKps, B * want * sizeof(orbx_keypoint)));
+        ORBX_HIP_TRY(hipMalloc((void**)&ex->d_outDesc, B * want * 32));
+        ex->outCap = want;
+    }
     s = ensure_host_staging(ex);
     if (s != ORBX_OK) return s;
     const size_t frameBytes = (size_t)width * height;

@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import KP_DTYPE, RECT_DTYPE, OrbxParams, check, lib, ptr
+from ._lib import KP_DTYPE, RECT_DTYPE, OrbxError, OrbxParams, check, lib, ptr
 
 
 class ORBextractor:
@@ -74,17 +74,32 @@ class ORBextractor:
         if image.strides[1] != 1:
             image = np.ascontiguousarray(image)
         h, w = image.shape
-        cap = self.max_keypoints
-        kps = np.zeros(cap, KP_DTYPE)
-        desc = np.zeros((cap, 32), np.uint8)
         n, mono = C.c_int(), C.c_int()
         rects = None
         if self.mvDynamicArea:
             rects = np.array([tuple(r) for r in self.mvDynamicArea], RECT_DTYPE)
-        check(self._L.orbx_extract(self._h, image.ctypes.data, w, h, image.strides[0], int(vLappingArea[0]),
-                                   int(vLappingArea[1]), ptr(rects), 0 if rects is None else len(rects), ptr(kps),
-                                   ptr(desc), cap, C.byref(n), C.byref(mono)))
+        while True:
+            cap = self.max_keypoints
+            kps = np.zeros(cap, KP_DTYPE)
+            desc = np.zeros((cap, 32), np.uint8)
+            try:
+                check(self._L.orbx_extract(self._h, image.ctypes.data, w, h, image.strides[0], int(vLappingArea[0]),
+                                           int(vLappingArea[1]), ptr(rects), 0 if rects is None else len(rects), ptr(kps),
+                                           ptr(desc), cap, C.byref(n), C.byref(mono)))
+                break
+            except OrbxError:
+                if not self._capacity_grew():
+                    raise
         return kps[:n.value].copy(), desc[:n.value].copy(), mono.value
+
+    def _capacity_grew(self):
+        """True if the geometry of the last image holds more keypoints than the arrays offered so far (an image of
+        another aspect ratio than the handle was created for): the caller offers larger arrays and calls again."""
+        now = self._L.orbx_extractor_max_keypoints(self._h)
+        if now <= self.max_keypoints:
+            return False
+        self.max_keypoints = now
+        return True
 
     def extract_batch(self, images, vLappingArea=(0, 0)):
         """One pass of every kernel over a list of equally sized host images.
@@ -95,13 +110,19 @@ class ORBextractor:
         h, w = imgs[0].shape
         assert all(im.shape == (h, w) and im.dtype == np.uint8 for im in imgs)
         ptrs = (C.c_void_p * nf)(*[im.ctypes.data for im in imgs])
-        cap = self.max_keypoints
-        kps = np.zeros((nf, cap), KP_DTYPE)
-        desc = np.zeros((nf, cap, 32), np.uint8)
         n = np.zeros(nf, np.int32)
         mono = np.zeros(nf, np.int32)
-        check(self._L.orbx_extract_batch(self._h, ptrs, nf, w, h, w, int(vLappingArea[0]), int(vLappingArea[1]),
-                                         ptr(kps), ptr(desc), cap, ptr(n), ptr(mono)))
+        while True:
+            cap = self.max_keypoints
+            kps = np.zeros((nf, cap), KP_DTYPE)
+            desc = np.zeros((nf, cap, 32), np.uint8)
+            try:
+                check(self._L.orbx_extract_batch(self._h, ptrs, nf, w, h, w, int(vLappingArea[0]), int(vLappingArea[1]),
+                                                 ptr(kps), ptr(desc), cap, ptr(n), ptr(mono)))
+                break
+            except OrbxError:
+                if not self._capacity_grew():
+                    raise
         return [(kps[f, :n[f]].copy(), desc[f, :n[f]].copy(), int(mono[f])) for f in range(nf)]
 
     def extract_batch_device(self, d_images, vLappingArea=(0, 0), out=None, stream=None):

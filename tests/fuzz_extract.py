@@ -2,7 +2,9 @@
 
     python tests/fuzz_extract.py [n_cases] [seed] [batch]
 
-With a third argument the device-resident batch entry point is used instead of the one-image host entry point:
+With "reuse" as third argument one handle (created for 2000 x 1300) serves ten consecutive cases of different
+sizes, images, lapping areas and rectangles (geometry rebuilt on every size change, refusals in between).
+With any other third argument the device-resident batch entry point is used instead of the one-image host entry point:
 1..8 frames per call in a device tensor whose rows and frames are padded by random amounts.
 
 Draws image size, pyramid shape, quota, thresholds, lapping area, erase rectangles and image kind at random, runs both
@@ -88,7 +90,9 @@ def run_batch(g, p, imgs, rng):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    batch = len(sys.argv) > 3
+    reuse = len(sys.argv) > 3 and sys.argv[3] == "reuse"
+    batch = len(sys.argv) > 3 and not reuse
+    shared, fixed = None, None
     O.build()
     O.lib()
     rng = np.random.default_rng(seed)
@@ -96,6 +100,40 @@ def main():
     t0 = time.time()
     for case in range(n):
         p = draw(rng, case)
+        if reuse:
+            if case % 10 == 0:
+                if shared is not None:
+                    shared.close()
+                    shared = None
+                fixed = {k: p[k] for k in ("nf", "sf", "nl", "ini", "mn")}
+                try:
+                    shared = A.ORBextractor(p["nf"], p["sf"], p["nl"], p["ini"], p["mn"], max_width=2000, max_height=1300)
+                except A.OrbxError as e:
+                    print(f"refused {p}: {e}", flush=True)
+            p.update(fixed)
+            if shared is None:
+                continue
+            img = image(p)
+            shared.mvDynamicArea = p["rects"]
+            try:
+                try:
+                    kg, dg, mg = shared(img, p["lap"])
+                except A.OrbxError as e:
+                    if e.status != -2:
+                        raise
+                    kg, dg, mg = shared(img, p["lap"])
+            except A.OrbxError as e:
+                print(f"refused {p}: {e}", flush=True)      # e.g. a top level of a few pixels for this size
+                continue
+            ko, do, mo = O.Extractor(p["nf"], p["sf"], p["nl"], p["ini"], p["mn"])(img, p["lap"], p["rects"])
+            same = mo == mg and len(ko) == len(kg) and np.array_equal(do, dg) and all(
+                np.array_equal(ko[x], kg[x]) for x in ("x", "y", "size", "angle", "response", "octave", "class_id"))
+            if not same:
+                bad += 1
+                print(f"DIFFERENT (shared handle) {p}: oracle {len(ko)} keypoints, handle {len(kg)}", flush=True)
+            if case % 10 == 9:
+                print(f"{case + 1} cases, {bad} different, {time.time() - t0:.0f} s", flush=True)
+            continue
         img = image(p)
         o = O.Extractor(p["nf"], p["sf"], p["nl"], p["ini"], p["mn"])
         nb = int(rng.integers(1, 9)) if batch else 1

@@ -234,6 +234,25 @@ def test_periodic_and_noise_images(oracle, w, h, nf):
     g.close()
 
 
+def test_wider_image_than_the_creation_size_holds_more_keypoints(oracle):
+    # A tiny quota on a very wide image: every level keeps one keypoint per non-empty quadtree root
+    # (ORBextractor.cc:665-700), more than the arrays sized for the creation size (few roots) can hold.
+    A = _gpu()
+    g = A.ORBextractor(30, 1.2, 8, 20, 7, max_width=1600, max_height=1200, max_batch=2)
+    o = oracle.Extractor(30, 1.2, 8, 20, 7)
+    cap0 = g.max_keypoints
+    wide = synth.scene(1600, 140, 91, n_prims=300)
+    ko, do, mo = o(wide, (0, 0))
+    assert len(ko) > cap0
+    _same(ko, do, mo, *g(wide, (0, 0)))
+    assert g.max_keypoints >= len(ko)
+    for kps, desc, mono in g.extract_batch([wide, wide[:, ::-1].copy()], (0, 0))[:1]:
+        _same(ko, do, mo, kps, desc, mono)
+    full = synth.scene(1600, 1200, 92)
+    _same(*o(full, (0, 0)), *g(full, (0, 0)))        # back to the creation size
+    g.close()
+
+
 def test_dynamic_rects(oracle):
     A = _gpu()
     img = synth.scene(640, 480, 5)
