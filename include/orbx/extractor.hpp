@@ -61,13 +61,20 @@ public:
                    std::vector<uint8_t>& descriptors, const std::vector<int>& vLappingArea) {
         if (!image || width <= 0 || height <= 0) { keypoints.clear(); descriptors.clear(); return -1; }
         ensure(width, height);
-        const int cap = orbx_extractor_max_keypoints(h_);
-        keypoints.resize(cap);
-        descriptors.resize((size_t)cap * 32);
+        int cap = orbx_extractor_max_keypoints(h_);
         int n = 0, mono = 0;
-        check(orbx_extract(h_, image, width, height, stride, vLappingArea.at(0), vLappingArea.at(1),
-                           mvDynamicArea.empty() ? nullptr : mvDynamicArea.data(), (int)mvDynamicArea.size(),
-                           keypoints.data(), descriptors.data(), cap, &n, &mono));
+        for (;;) {
+            keypoints.resize(cap);
+            descriptors.resize((size_t)cap * 32);
+            const orbx_status s = orbx_extract(h_, image, width, height, stride, vLappingArea.at(0), vLappingArea.at(1),
+                                               mvDynamicArea.empty() ? nullptr : mvDynamicArea.data(),
+                                               (int)mvDynamicArea.size(), keypoints.data(), descriptors.data(), cap, &n, &mono);
+            // the maximum follows the image size (see orbx_extractor_max_keypoints): another size may need larger arrays
+            const int now = orbx_extractor_max_keypoints(h_);
+            if (s == ORBX_ERR_CAPACITY && now > cap) { cap = now; continue; }
+            check(s);
+            break;
+        }
         keypoints.resize(n);
         descriptors.resize((size_t)n * 32);
         if (keepPyramid) fetch_pyramid();
@@ -82,11 +89,17 @@ public:
         *n = 0;
         if (!image || width <= 0 || height <= 0) return -1;
         ensure(width, height);
-        const int cap = orbx_extractor_max_keypoints(h_);
+        int cap = orbx_extractor_max_keypoints(h_);
         int mono = 0;
-        check(orbx_extract(h_, image, width, height, stride, vLappingArea.at(0), vLappingArea.at(1),
-                           mvDynamicArea.empty() ? nullptr : mvDynamicArea.data(), (int)mvDynamicArea.size(),
-                           keypointStorage(cap), descriptorStorage(cap), cap, n, &mono));
+        for (;;) {
+            const orbx_status s = orbx_extract(h_, image, width, height, stride, vLappingArea.at(0), vLappingArea.at(1),
+                                               mvDynamicArea.empty() ? nullptr : mvDynamicArea.data(),
+                                               (int)mvDynamicArea.size(), keypointStorage(cap), descriptorStorage(cap), cap, n, &mono);
+            const int now = orbx_extractor_max_keypoints(h_);
+            if (s == ORBX_ERR_CAPACITY && now > cap) { cap = now; continue; }     // another image size: larger storage
+            check(s);
+            break;
+        }
         return mono;
     }
 
