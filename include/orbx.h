@@ -555,6 +555,24 @@ orbx_status orbx_search_for_triangulation_cameras(const orbx_keypoint* kps1, con
                                                   int n_buckets, const orbx_triangulation_geometry* geom, int only_stereo,
                                                   int coarse, int check_orientation, int* matches12, int* n_matches);
 
+/* The camera-model calls that the search above and orbx_stereo_fisheye_matches evaluate per candidate, on their own for
+ * n points / pairs at once (host arithmetic in binary32 as in the reference, no device involved):
+ *   orbx_camera_project              GeometricCamera::project(const Eigen::Vector3f&)   Pinhole.cpp:46-53, KannalaBrandt8.cpp:66-83
+ *   orbx_camera_unproject            GeometricCamera::unprojectEig                      Pinhole.cpp:66-70, KannalaBrandt8.cpp:111-146
+ *   orbx_camera_triangulate_matches  KannalaBrandt8::TriangulateMatches                 KannalaBrandt8.cpp:323-397 (Triangulate :418-430)
+ *   orbx_camera_epipolar_constrain   GeometricCamera::epipolarConstrain                 Pinhole.cpp:118-141, KannalaBrandt8.cpp:227-232
+ * xyz / rays: n x 3, uv: n x 2, R12 row-major 3x3 with x1 = R12 x2 + t12; sigma_level[i] / unc[i] = mvLevelSigma2 of the two
+ * keypoints' octaves.  depth[i] = TriangulateMatches' return value (depth in camera 1, or -1 parallax, -2 / -3 behind a
+ * camera, -4 / -5 reprojection error); points3d (n x 3, may be NULL) is written for accepted pairs only. */
+orbx_status orbx_camera_project(const orbx_camera_model* cam, const float* xyz, int n, float* uv);
+orbx_status orbx_camera_unproject(const orbx_camera_model* cam, const float* uv, int n, float* rays);
+orbx_status orbx_camera_triangulate_matches(const orbx_camera_model* cam1, const orbx_camera_model* cam2, const float* uv1,
+                                            const float* uv2, int n, const float* R12, const float* t12,
+                                            const float* sigma_level, const float* unc, float* depth, float* points3d);
+orbx_status orbx_camera_epipolar_constrain(const orbx_camera_model* cam1, const orbx_camera_model* cam2, const float* uv1,
+                                           const float* uv2, int n, const float* R12, const float* t12,
+                                           const float* sigma_level, const float* unc, uint8_t* accepted);
+
 /* The three bucketed searches on resident frames (orbx_frame holds mDescriptors on the device and the keypoints'
  * angles, levels and mvuRight on the host): the same loops, results and order as the functions of the same name
  * without "frame", minus the upload of both descriptor sets -- the FeatureVector CSR arrays go in and the distance

@@ -20,8 +20,8 @@ assert KP_DTYPE.itemsize == 28
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "orb_oracle.cpp")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("orb_oracle.cpp", "camera_oracle.cpp", "camera_oracle.h")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
@@ -111,15 +111,20 @@ def lib():
         L.orc_search_window_best_stereo.restype = C.c_int
         L.orc_search_window_best_stereo.argtypes = ([C.c_void_p] * 3 + [C.c_int]) * 2 + [C.c_void_p] * 11 + [C.c_int, C.c_float] + [C.c_void_p] * 3 + [C.c_float, C.c_void_p]
         L.orc_search_for_triangulation_cameras.restype = C.c_int
-        L.orc_search_for_triangulation_cameras.argtypes = ([C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]) * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_float, C.c_float] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]
+        L.orc_search_for_triangulation_cameras.argtypes = ([C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]) * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_float, C.c_float] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]
         L.orc_kb8_triangulate_matches.restype = C.c_float
         L.orc_kb8_triangulate_matches.argtypes = [C.c_void_p, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_float, C.c_float]
         L.orc_stereo_fisheye_matches.restype = C.c_int
-        L.orc_stereo_fisheye_matches.argtypes = ([C.c_void_p, C.c_void_p, C.c_int, C.c_int]) * 2 + [C.c_void_p] * 9
+        L.orc_stereo_fisheye_matches.argtypes = ([C.c_void_p, C.c_void_p, C.c_int, C.c_int]) * 2 + [C.c_void_p] * 10
+        L.orc_triangulate_matches.restype = C.c_double
+        L.orc_triangulate_matches.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_epipolar_constrain_margin.restype = C.c_int
+        L.orc_epipolar_constrain_margin.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.orc_camera_project.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_camera_unproject.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_epipolar_constrain.restype = C.c_int
         L.orc_epipolar_constrain.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+        L.orc_camera_gates_many.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 9
         _lib = L
     return _lib
 
@@ -515,8 +520,8 @@ def search_for_triangulation(kps1, desc1, free1, ur1, idx1, off1, kps2, desc2, f
     n = lib().orc_search_for_triangulation(_p(kps1), _p(desc1), _p(a[0]), _p(a[1]), len(kps1), _p(a[2]), _p(a[3]),
                                            _p(kps2), _p(desc2), _p(b[0]), _p(b[1]), len(kps2), _p(b[2]), _p(b[3]),
                                            len(a[3]) - 1, _p(F), float(ep[0]), float(ep[1]), _p(sf), _p(sg),
-                                           int(only_stereo), int(coarse), int(check_ori), _p(out))
-    return out, n
+                                           int(only_stereo), int(coarse), int(check_ori), _p(out), _p(margin))
+    return (out, n, margin) if with_margin else (out, n)
 
 
 def bow_transform(child_off, child_idx, node_desc, word_id, weight, depth, desc, levelsup):
@@ -589,9 +594,10 @@ def search_window_best_stereo(gridL: Grid, descL, gridR, descR, left, right, qde
 
 def search_for_triangulation_cameras(kps1, desc1, free1, ur1, n_left1, idx1, off1, kps2, desc2, free2, ur2, n_left2,
                                      idx2, off2, cam_types, cam_params, poses, ep, scale_factors2, level_sigma2_1,
-                                     level_sigma2_2, only_stereo, coarse, check_ori):
+                                     level_sigma2_2, only_stereo, coarse, check_ori, with_margin=False):
     """cam_types[4], cam_params[4][8] = {cam1 left, cam1 right, cam2 left, cam2 right}; poses[4][12] = ll, lr, rl, rr as
-    (R12 row-major, t12)."""
+    (R12 row-major, t12).  with_margin: also the per-keypoint rounding margin of the gates evaluated for it (< 1: the
+    keypoint's outcome may differ under binary32 rounding, see camera_oracle.cpp)."""
     kps1, kps2 = np.ascontiguousarray(kps1), np.ascontiguousarray(kps2)
     desc1, desc2 = _u8(desc1), _u8(desc2)
     a = [_u8(free1), None if ur1 is None else _f32(ur1), _i32(idx1), _i32(off1)]
@@ -599,12 +605,13 @@ def search_for_triangulation_cameras(kps1, desc1, free1, ur1, n_left1, idx1, off
     ct, cp, ps = _i32(cam_types), _f32(cam_params).reshape(32), _f32(poses).reshape(48)
     sf, s1, s2 = _f32(scale_factors2), _f32(level_sigma2_1), _f32(level_sigma2_2)
     out = np.zeros(len(kps1), np.int32)
+    margin = np.zeros(len(kps1), np.float64)
     n = lib().orc_search_for_triangulation_cameras(
         _p(kps1), _p(desc1), _p(a[0]), _p(a[1]), len(kps1), n_left1, _p(a[2]), _p(a[3]),
         _p(kps2), _p(desc2), _p(b[0]), _p(b[1]), len(kps2), n_left2, _p(b[2]), _p(b[3]), len(a[3]) - 1,
         _p(ct), _p(cp), _p(ps), float(ep[0]), float(ep[1]), _p(sf), _p(s1), _p(s2),
-        int(only_stereo), int(coarse), int(check_ori), _p(out))
-    return out, n
+        int(only_stereo), int(coarse), int(check_ori), _p(out), _p(margin))
+    return (out, n, margin) if with_margin else (out, n)
 
 
 def camera_project(cam_type, params, xyz):
@@ -624,19 +631,51 @@ def kb8_triangulate_matches(cam1, cam2, p1, p2, R12, t12, sigma1, sigma2):
                                                    float(p2[1]), _p(_f32(R12).reshape(9)), _p(_f32(t12)), sigma1, sigma2))
 
 
-def stereo_fisheye_matches(kpsL, descL, mono_left, kpsR, descR, mono_right, cam1, cam2, Rlr, tlr, level_sigma2):
-    """Frame::ComputeStereoFishEyeMatches: (left_to_right, right_to_left, depth, points3d, nMatches)."""
+def stereo_fisheye_matches(kpsL, descL, mono_left, kpsR, descR, mono_right, cam1, cam2, Rlr, tlr, level_sigma2,
+                           with_margin=False):
+    """Frame::ComputeStereoFishEyeMatches: (left_to_right, right_to_left, depth, points3d, nMatches[, margin])."""
     kpsL, kpsR = np.ascontiguousarray(kpsL), np.ascontiguousarray(kpsR)
     descL, descR = _u8(descL), _u8(descR)
     nL, nR = len(kpsL), len(kpsR)
     l2r, r2l = np.zeros(nL, np.int32), np.zeros(nR, np.int32)
     depth, p3d = np.zeros(nL, np.float32), np.zeros((nL, 3), np.float32)
+    margin = np.zeros(nL, np.float64)
     n = lib().orc_stereo_fisheye_matches(_p(kpsL), _p(descL), nL, mono_left, _p(kpsR), _p(descR), nR, mono_right,
                                          _p(_f32(cam1)), _p(_f32(cam2)), _p(_f32(Rlr).reshape(9)), _p(_f32(tlr)),
-                                         _p(_f32(level_sigma2)), _p(l2r), _p(r2l), _p(depth), _p(p3d))
-    return l2r, r2l, depth, p3d, n
+                                         _p(_f32(level_sigma2)), _p(l2r), _p(r2l), _p(depth), _p(p3d), _p(margin))
+    return (l2r, r2l, depth, p3d, n, margin) if with_margin else (l2r, r2l, depth, p3d, n)
+
+
+def triangulate_matches(type1, cam1, type2, cam2, p1, p2, R12, t12, sigma1, sigma2):
+    """TriangulateMatches in binary64: (depth or rejection code, point[3], rounding margin)."""
+    p3d = np.zeros(3, np.float64)
+    m = np.zeros(1, np.float64)
+    z = lib().orc_triangulate_matches(type1, _p(_f32(cam1)), type2, _p(_f32(cam2)), float(p1[0]), float(p1[1]), float(p2[0]),
+                                      float(p2[1]), _p(_f32(R12).reshape(9)), _p(_f32(t12)), sigma1, sigma2, _p(p3d), _p(m))
+    return float(z), p3d, float(m[0])
+
+
+def epipolar_constrain_margin(type1, cam1, type2, cam2, p1, p2, R12, t12, sigma1, sigma2):
+    m = np.zeros(1, np.float64)
+    ok = lib().orc_epipolar_constrain_margin(type1, _p(_f32(cam1)), type2, _p(_f32(cam2)), float(p1[0]), float(p1[1]),
+                                             float(p2[0]), float(p2[1]), _p(_f32(R12).reshape(9)), _p(_f32(t12)), sigma1,
+                                             sigma2, _p(m))
+    return bool(ok), float(m[0])
 
 
 def epipolar_constrain(type1, cam1, type2, cam2, p1, p2, R12, t12, sigma1, sigma2):
     return bool(lib().orc_epipolar_constrain(type1, _p(_f32(cam1)), type2, _p(_f32(cam2)), float(p1[0]), float(p1[1]),
                                              float(p2[0]), float(p2[1]), _p(_f32(R12).reshape(9)), _p(_f32(t12)), sigma1, sigma2))
+
+
+def camera_gates_many(type1, cam1, type2, cam2, uv1, uv2, R12, t12, sigma1, sigma2):
+    """The binary64 gates for n pairs: dict(depth, tri_margin, p3d, accepted, epi_margin)."""
+    uv1, uv2 = _f32(uv1).reshape(-1, 2), _f32(uv2).reshape(-1, 2)
+    n = len(uv1)
+    s1 = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma1, np.float32), (n,)))
+    s2 = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma2, np.float32), (n,)))
+    depth, tm, em = np.zeros(n), np.full(n, 1e300), np.full(n, 1e300)
+    p3d, acc = np.zeros((n, 3)), np.zeros(n, np.uint8)
+    lib().orc_camera_gates_many(type1, _p(_f32(cam1)), type2, _p(_f32(cam2)), _p(uv1), _p(uv2), n, _p(_f32(R12).reshape(9)),
+                                _p(_f32(t12)), _p(s1), _p(s2), _p(depth), _p(tm), _p(p3d), _p(acc), _p(em))
+    return dict(depth=depth, tri_margin=tm, p3d=p3d, accepted=acc.astype(bool), epi_margin=em)

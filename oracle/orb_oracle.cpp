@@ -36,8 +36,8 @@
 #include <utility>
 #include <vector>
 
-// camera-model gates of SearchForTriangulation: shared with the library (see the header for why)
-#include "../orb_slam3_amd/csrc/orbx_camera_gates.h"
+// camera-model gates of SearchForTriangulation / ComputeStereoFishEyeMatches: the oracle's own binary64 restatement
+#include "camera_oracle.h"
 
 namespace {
 
@@ -1584,10 +1584,15 @@ int orc_search_by_projection_stereo(void* gridL, const void* kpsL_, const uint8_
                     if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kL[idx].octave; bestIdx = idx; }
                     else if (dist < bestDist2) { bestLevel2 = kL[idx].octave; bestDist2 = dist; }
                 }
-                if (bestDist <= 100 && !(bestLevel == bestLevel2 && bestDist > nnratio * bestDist2)) {
-                    kp_query[bestIdx] = q; taken[bestIdx] = mark;
-                    if (l2r && l2r[bestIdx] != -1) { kp_query[l2r[bestIdx] + nL] = q; taken[l2r[bestIdx] + nL] = mark; nmatches++; }
-                    nmatches++;
+                if (bestDist <= 100) {
+                    // :125-126 -- this `continue` leaves the map-point iteration: a failed ratio test in the left
+                    // image also skips the right-camera pass (:146-213) of this map point
+                    if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+                    if (bestLevel != bestLevel2 || bestDist <= nnratio * bestDist2) {
+                        kp_query[bestIdx] = q; taken[bestIdx] = mark;
+                        if (l2r && l2r[bestIdx] != -1) { kp_query[l2r[bestIdx] + nL] = q; taken[l2r[bestIdx] + nL] = mark; nmatches++; }
+                        nmatches++;
+                    }
                 }
             }
         }
@@ -1683,14 +1688,18 @@ int orc_search_for_triangulation_cameras(const void* kps1_, const uint8_t* desc1
                                          const int* camTypes, const float* camParams, const float* poses,
                                          float epx, float epy, const float* scaleFactors2, const float* levelSigma2_1,
                                          const float* levelSigma2_2, int bOnlyStereo, int bCoarse, int checkOrientation,
-                                         int* vMatches12) {
+                                         int* vMatches12, double* margin1) {
     const KeyPt* k1 = (const KeyPt*)kps1_;
     const KeyPt* k2 = (const KeyPt*)kps2_;
     (void)n2;
-    orbx_gates::Camera cams[4];
-    for (int c = 0; c < 4; ++c) { cams[c].type = camTypes[c]; for (int k = 0; k < 8; ++k) cams[c].p[k] = camParams[8 * c + k]; }
+    // margin1[id1] (may be null): the smallest rounding margin of any gate evaluated for keypoint id1 (see
+    // camera_oracle.cpp); < 1 means the outcome for id1 may legitimately differ under binary32 rounding.
+    camo::Cam cams[4];
+    for (int c = 0; c < 4; ++c) cams[c] = camo::make_cam(camTypes[c], camParams + 8 * c);
+    double posesD[48];
+    for (int i = 0; i < 48; ++i) posesD[i] = poses[i];
     const bool twoCams = nLeft1 != -1 && nLeft2 != -1;
-    for (int i = 0; i < n1; ++i) vMatches12[i] = -1;
+    for (int i = 0; i < n1; ++i) { vMatches12[i] = -1; if (margin1) margin1[i] = 1e300; }
     std::vector<int> rotHist[HISTO_LENGTH];
     const float factor = 1.0f / HISTO_LENGTH;
     int nmatches = 0;
@@ -1718,14 +1727,18 @@ int orc_search_for_triangulation_cameras(const void* kps1_, const uint8_t* desc1
                 }
                 int sel = 0;
                 if (twoCams) sel = (bRight1 ? 2 : 0) + (bRight2 ? 1 : 0);
-                const orbx_gates::Camera& c1 = cams[twoCams && bRight1 ? 1 : 0];
-                const orbx_gates::Camera& c2 = cams[2 + (twoCams && bRight2 ? 1 : 0)];
-                const float* R12 = poses + 12 * sel;
-                const float* t12 = R12 + 9;
-                if (bCoarse || orbx_gates::epipolar_constrain(c1, c2, kp1.x, kp1.y, kp2.x, kp2.y, R12, t12,
-                                                              levelSigma2_1[kp1.octave], levelSigma2_2[kp2.octave])) {
-                    bestIdx2 = id2; bestDist = dist;
+                const camo::Cam& c1 = cams[twoCams && bRight1 ? 1 : 0];
+                const camo::Cam& c2 = cams[2 + (twoCams && bRight2 ? 1 : 0)];
+                const double* R12 = posesD + 12 * sel;
+                const double* t12 = R12 + 9;
+                bool ok = bCoarse != 0;
+                if (!ok) {
+                    double m = 1e300;
+                    ok = camo::epipolar_constrain(c1, c2, kp1.x, kp1.y, kp2.x, kp2.y, R12, t12, levelSigma2_1[kp1.octave],
+                                                  levelSigma2_2[kp2.octave], &m);
+                    if (margin1 && m < margin1[id1]) margin1[id1] = m;
                 }
+                if (ok) { bestIdx2 = id2; bestDist = dist; }
             }
             if (bestIdx2 >= 0) {
                 vMatches12[id1] = bestIdx2;
@@ -1744,66 +1757,44 @@ int orc_search_for_triangulation_cameras(const void* kps1_, const uint8_t* desc1
     return nmatches;
 }
 
-// The camera gates on their own (known-answer tests).
-float orc_kb8_triangulate_matches(const float* cam1, const float* cam2, float u1, float v1, float u2, float v2,
-                                  const float* R12, const float* t12, float sigmaLevel, float unc) {
-    orbx_gates::Camera c1, c2;
-    c1.type = c2.type = orbx_gates::kKannalaBrandt8;
-    for (int k = 0; k < 8; ++k) { c1.p[k] = cam1[k]; c2.p[k] = cam2[k]; }
-    return orbx_gates::triangulate_matches(c1, c2, u1, v1, u2, v2, R12, t12, sigmaLevel, unc);
-}
 // Frame::ComputeStereoFishEyeMatches (Frame.cc:1286-1338): knnMatch(k = 2) of the lapping-area descriptors, ratio 0.7,
-// TriangulateMatches, depth > 0.0001.  Returns nMatches.
+// TriangulateMatches, depth > 0.0001.  Returns nMatches.  margin[q] (may be null): rounding margin of left keypoint q's
+// TriangulateMatches call (1e300 when none was made), see camera_oracle.cpp.
 int orc_stereo_fisheye_matches(const void* kL_, const uint8_t* dL, int nL, int monoL, const void* kR_,
                                const uint8_t* dR, int nR, int monoR, const float* cam1, const float* cam2, const float* Rlr,
-                               const float* tlr, const float* sigma2, int* l2r, int* r2l, float* depth, float* p3d) {
+                               const float* tlr, const float* sigma2, int* l2r, int* r2l, float* depth, float* p3d,
+                               double* margin) {
     const KeyPt* kL = (const KeyPt*)kL_;
     const KeyPt* kR = (const KeyPt*)kR_;
-    for (int i = 0; i < nL; ++i) { l2r[i] = -1; depth[i] = -1.f; }
+    for (int i = 0; i < nL; ++i) { l2r[i] = -1; depth[i] = -1.f; if (margin) margin[i] = 1e300; }
     for (int i = 0; i < nR; ++i) r2l[i] = -1;
-    orbx_gates::Camera c1, c2;
-    c1.type = c2.type = orbx_gates::kKannalaBrandt8;
-    for (int k = 0; k < 8; ++k) { c1.p[k] = cam1[k]; c2.p[k] = cam2[k]; }
+    const camo::Cam c1 = camo::make_cam(camo::kKannalaBrandt8, cam1), c2 = camo::make_cam(camo::kKannalaBrandt8, cam2);
+    double R[9], t[3];
+    for (int i = 0; i < 9; ++i) R[i] = Rlr[i];
+    for (int i = 0; i < 3; ++i) t[i] = tlr[i];
     int nMatches = 0;
     for (int q = monoL; q < nL; ++q) {
         // the two nearest right descriptors, the lower index first among equals (BFMatcher's order)
         int best = INT32_MAX, second = INT32_MAX, bestIdx = -1, secondIdx = -1;
-        for (int t = monoR; t < nR; ++t) {
+        for (int tr = monoR; tr < nR; ++tr) {
             int d = 0;
-            for (int k = 0; k < 32; ++k) d += __builtin_popcount((unsigned)(dL[(size_t)q * 32 + k] ^ dR[(size_t)t * 32 + k]));
-            if (d < best) { second = best; secondIdx = bestIdx; best = d; bestIdx = t; }
-            else if (d < second) { second = d; secondIdx = t; }
+            for (int k = 0; k < 32; ++k) d += __builtin_popcount((unsigned)(dL[(size_t)q * 32 + k] ^ dR[(size_t)tr * 32 + k]));
+            if (d < best) { second = best; secondIdx = bestIdx; best = d; bestIdx = tr; }
+            else if (d < second) { second = d; secondIdx = tr; }
         }
         if (secondIdx < 0) continue;
         if (!((float)best < (float)second * 0.7)) continue;
-        orbx_gates::Vec3 P{0.f, 0.f, 0.f};
-        const float z = orbx_gates::triangulate_matches(c1, c2, kL[q].x, kL[q].y, kR[bestIdx].x, kR[bestIdx].y, Rlr, tlr,
-                                                        sigma2[kL[q].octave], sigma2[kR[bestIdx].octave], &P);
-        if (z > 0.0001f) {
-            l2r[q] = bestIdx; r2l[bestIdx] = q; depth[q] = z;
-            p3d[3 * q] = P.x; p3d[3 * q + 1] = P.y; p3d[3 * q + 2] = P.z;
+        double P[3] = {0, 0, 0}, m = 1e300;
+        const double z = camo::triangulate_matches(c1, c2, kL[q].x, kL[q].y, kR[bestIdx].x, kR[bestIdx].y, R, t,
+                                                   sigma2[kL[q].octave], sigma2[kR[bestIdx].octave], P, &m);
+        if (margin) margin[q] = m;
+        if (z > 0.0001) {
+            l2r[q] = bestIdx; r2l[bestIdx] = q; depth[q] = (float)z;
+            p3d[3 * q] = (float)P[0]; p3d[3 * q + 1] = (float)P[1]; p3d[3 * q + 2] = (float)P[2];
             ++nMatches;
         }
     }
     return nMatches;
-}
-void orc_camera_project(int type, const float* params, const float* xyz, float* uv) {
-    orbx_gates::Camera c; c.type = type;
-    for (int k = 0; k < 8; ++k) c.p[k] = params[k];
-    orbx_gates::project(c, orbx_gates::Vec3{xyz[0], xyz[1], xyz[2]}, &uv[0], &uv[1]);
-}
-void orc_camera_unproject(int type, const float* params, const float* uv, float* xyz) {
-    orbx_gates::Camera c; c.type = type;
-    for (int k = 0; k < 8; ++k) c.p[k] = params[k];
-    const orbx_gates::Vec3 r = orbx_gates::unproject(c, uv[0], uv[1]);
-    xyz[0] = r.x; xyz[1] = r.y; xyz[2] = r.z;
-}
-int orc_epipolar_constrain(int type1, const float* cam1, int type2, const float* cam2, float u1, float v1, float u2, float v2,
-                           const float* R12, const float* t12, float sigmaLevel, float unc) {
-    orbx_gates::Camera c1, c2;
-    c1.type = type1; c2.type = type2;
-    for (int k = 0; k < 8; ++k) { c1.p[k] = cam1[k]; c2.p[k] = cam2[k]; }
-    return orbx_gates::epipolar_constrain(c1, c2, u1, v1, u2, v2, R12, t12, sigmaLevel, unc) ? 1 : 0;
 }
 
 }  // extern "C"

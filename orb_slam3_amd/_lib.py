@@ -101,6 +101,10 @@ PROTOTYPES = {
     "orbx_bow_vectors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orbx_scale_tables": (C.c_int, [C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orbx_stereo_fisheye_matches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "orbx_camera_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "orbx_camera_unproject": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "orbx_camera_triangulate_matches": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "orbx_camera_epipolar_constrain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "orbx_archive_read_matrix": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p, C.c_size_t]),
     "orbx_archive_write_matrix": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "orbx_archive_read_keypoints": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t), C.c_void_p, C.c_int, C.POINTER(C.c_int)]),

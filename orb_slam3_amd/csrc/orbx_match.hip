@@ -1258,6 +1258,64 @@ extern "C" orbx_status orbx_stereo_fisheye_matches(const orbx_keypoint* kps_left
     return ORBX_OK;
 }
 
+// ---- the camera-model calls on their own (host arithmetic only) ------------------------------------------
+static orbx_gates::Camera gate_camera(const orbx_camera_model* m) {
+    orbx_gates::Camera c;
+    c.type = m->type;
+    for (int k = 0; k < 8; ++k) c.p[k] = m->params[k];
+    return c;
+}
+static bool gate_camera_ok(const orbx_camera_model* m) {
+    return m && (m->type == ORBX_CAMERA_PINHOLE || m->type == ORBX_CAMERA_KANNALA_BRANDT8);
+}
+
+extern "C" orbx_status orbx_camera_project(const orbx_camera_model* cam, const float* xyz, int n, float* uv) {
+    ORBX_REQUIRE(gate_camera_ok(cam) && n >= 0 && (n == 0 || (xyz && uv)), "bad camera model or null argument");
+    const orbx_gates::Camera c = gate_camera(cam);
+    for (int i = 0; i < n; ++i)
+        orbx_gates::project(c, orbx_gates::Vec3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]}, &uv[2 * i], &uv[2 * i + 1]);
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_camera_unproject(const orbx_camera_model* cam, const float* uv, int n, float* rays) {
+    ORBX_REQUIRE(gate_camera_ok(cam) && n >= 0 && (n == 0 || (uv && rays)), "bad camera model or null argument");
+    const orbx_gates::Camera c = gate_camera(cam);
+    for (int i = 0; i < n; ++i) {
+        const orbx_gates::Vec3 r = orbx_gates::unproject(c, uv[2 * i], uv[2 * i + 1]);
+        rays[3 * i] = r.x; rays[3 * i + 1] = r.y; rays[3 * i + 2] = r.z;
+    }
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_camera_triangulate_matches(const orbx_camera_model* cam1, const orbx_camera_model* cam2,
+                                                       const float* uv1, const float* uv2, int n, const float* R12,
+                                                       const float* t12, const float* sigma_level, const float* unc,
+                                                       float* depth, float* points3d) {
+    ORBX_REQUIRE(gate_camera_ok(cam1) && gate_camera_ok(cam2) && R12 && t12 && n >= 0, "bad camera model or null argument");
+    ORBX_REQUIRE(n == 0 || (uv1 && uv2 && sigma_level && unc && depth), "null argument");
+    const orbx_gates::Camera c1 = gate_camera(cam1), c2 = gate_camera(cam2);
+    for (int i = 0; i < n; ++i) {
+        orbx_gates::Vec3 P{0.f, 0.f, 0.f};
+        depth[i] = orbx_gates::triangulate_matches(c1, c2, uv1[2 * i], uv1[2 * i + 1], uv2[2 * i], uv2[2 * i + 1], R12, t12,
+                                                   sigma_level[i], unc[i], &P);
+        if (points3d && depth[i] > 0) { points3d[3 * i] = P.x; points3d[3 * i + 1] = P.y; points3d[3 * i + 2] = P.z; }
+    }
+    return ORBX_OK;
+}
+
+extern "C" orbx_status orbx_camera_epipolar_constrain(const orbx_camera_model* cam1, const orbx_camera_model* cam2,
+                                                      const float* uv1, const float* uv2, int n, const float* R12,
+                                                      const float* t12, const float* sigma_level, const float* unc,
+                                                      uint8_t* accepted) {
+    ORBX_REQUIRE(gate_camera_ok(cam1) && gate_camera_ok(cam2) && R12 && t12 && n >= 0, "bad camera model or null argument");
+    ORBX_REQUIRE(n == 0 || (uv1 && uv2 && sigma_level && unc && accepted), "null argument");
+    const orbx_gates::Camera c1 = gate_camera(cam1), c2 = gate_camera(cam2);
+    for (int i = 0; i < n; ++i)
+        accepted[i] = orbx_gates::epipolar_constrain(c1, c2, uv1[2 * i], uv1[2 * i + 1], uv2[2 * i], uv2[2 * i + 1], R12, t12,
+                                                     sigma_level[i], unc[i]) ? 1 : 0;
+    return ORBX_OK;
+}
+
 struct orbx_frame {
     int device = -1;       // where the features live; searches switch the calling thread to it
     int n = 0;
@@ -1856,7 +1914,10 @@ extern "C" orbx_status orbx_frame_search_by_projection_stereo(const orbx_frame* 
                 if (d < best) { best2 = best; best = d; bestLevel2 = bestLevel; bestLevel = kL[i].octave; bestIdx = i; }
                 else if (d < best2) { bestLevel2 = kL[i].octave; best2 = d; }
             }
-            if (best <= 100 && !(bestLevel == bestLevel2 && best > nn_ratio * best2)) {
+            // :123-126: a left best within TH_HIGH that fails the ratio test ends this map point -- the reference's
+            // `continue` sits in the map-point loop, so the right-camera pass below is skipped as well
+            if (best <= 100 && bestLevel == bestLevel2 && best > nn_ratio * best2) continue;
+            if (best <= 100) {
                 kp_query[bestIdx] = q; taken[bestIdx] = mark;
                 if (nR > 0 && left_to_right && left_to_right[bestIdx] != -1) {       // the stereo observation in the right camera
                     const int r = left_to_right[bestIdx];

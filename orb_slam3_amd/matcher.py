@@ -471,6 +471,60 @@ class CameraModel(C.Structure):
     _fields_ = [("type", C.c_int), ("params", C.c_float * 8)]
 
 
+def camera_model(cam_type: int, params) -> "CameraModel":
+    """orbx_camera_model from GeometricCamera::mvParameters: 0 = Pinhole {fx, fy, cx, cy}, 1 = KannalaBrandt8 {+ k0..k3}."""
+    m = CameraModel()
+    m.type = int(cam_type)
+    p = [float(v) for v in params] + [0.0] * 8
+    m.params[:] = p[:8]
+    return m
+
+
+def _f32c(a, shape=None):
+    a = np.ascontiguousarray(a, np.float32)
+    return a if shape is None else a.reshape(shape)
+
+
+def camera_project(cam: "CameraModel", xyz):
+    """GeometricCamera::project(Eigen::Vector3f) for n points [n, 3] -> [n, 2] (host arithmetic)."""
+    xyz = _f32c(xyz, (-1, 3))
+    uv = np.zeros((len(xyz), 2), np.float32)
+    check(lib().orbx_camera_project(C.addressof(cam), ptr(xyz), len(xyz), ptr(uv)))
+    return uv
+
+
+def camera_unproject(cam: "CameraModel", uv):
+    """GeometricCamera::unprojectEig for n image points [n, 2] -> rays [n, 3]."""
+    uv = _f32c(uv, (-1, 2))
+    rays = np.zeros((len(uv), 3), np.float32)
+    check(lib().orbx_camera_unproject(C.addressof(cam), ptr(uv), len(uv), ptr(rays)))
+    return rays
+
+
+def camera_triangulate_matches(cam1, cam2, uv1, uv2, R12, t12, sigma1, sigma2):
+    """KannalaBrandt8::TriangulateMatches for n pairs: (depth or rejection code [n], points [n, 3])."""
+    uv1, uv2 = _f32c(uv1, (-1, 2)), _f32c(uv2, (-1, 2))
+    n = len(uv1)
+    s1 = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma1, np.float32), (n,)))
+    s2 = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma2, np.float32), (n,)))
+    depth, p3d = np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
+    check(lib().orbx_camera_triangulate_matches(C.addressof(cam1), C.addressof(cam2), ptr(uv1), ptr(uv2), n,
+                                                ptr(_f32c(R12, 9)), ptr(_f32c(t12, 3)), ptr(s1), ptr(s2), ptr(depth), ptr(p3d)))
+    return depth, p3d
+
+
+def camera_epipolar_constrain(cam1, cam2, uv1, uv2, R12, t12, sigma1, sigma2):
+    """pCamera1->epipolarConstrain(pCamera2, kp1, kp2, R12, t12, sigma1, sigma2) for n pairs -> bool [n]."""
+    uv1, uv2 = _f32c(uv1, (-1, 2)), _f32c(uv2, (-1, 2))
+    n = len(uv1)
+    s1 = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma1, np.float32), (n,)))
+    s2 = np.ascontiguousarray(np.broadcast_to(np.asarray(sigma2, np.float32), (n,)))
+    ok = np.zeros(n, np.uint8)
+    check(lib().orbx_camera_epipolar_constrain(C.addressof(cam1), C.addressof(cam2), ptr(uv1), ptr(uv2), n,
+                                               ptr(_f32c(R12, 9)), ptr(_f32c(t12, 3)), ptr(s1), ptr(s2), ptr(ok)))
+    return ok.astype(bool)
+
+
 class RelPose(C.Structure):
     """orbx_rel_pose."""
     _fields_ = [("R12", C.c_float * 9), ("t12", C.c_float * 3)]

@@ -109,6 +109,39 @@ def test_search_by_projection_both_cameras(oracle, fisheye_frame, seed, th, two)
         assert len(both) > 5
 
 
+def test_left_ratio_failure_skips_the_right_camera_pass(oracle):
+    """ORBmatcher.cc:125-126 leaves the map-point loop: a left best within TH_HIGH that fails the ratio test gets no
+    right-camera pass.  Fixture: 200 map points with two equally good left candidates on one level and one clear
+    right match each (tests/replay_two_cameras.py).  The library must equal the oracle and an independent Python
+    transcription of :42-216; the transcription with the exit misread must differ."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import replay_two_cameras as R
+    A = _gpu()
+    kL, dL, kR, dR, ql, qr, qdesc, l2r, r2l, half = R.ambiguous_left_fixture(3, 400, synth.KP_DTYPE, synth.QUERY_DTYPE)
+    gL, gR = oracle.Grid(kL, *BOUNDS), oracle.Grid(kR, *BOUNDS)
+    rng = np.random.default_rng(9)
+    taken0 = (rng.random(len(kL) + len(kR)) < 0.05).astype(np.uint8)
+    marks = (rng.random(len(ql)) < 0.9).astype(np.uint8)
+    lvl = ql["max_level"].astype(np.int32)
+    kpq_o, taken_o, n_o = oracle.search_by_projection_stereo(
+        gL, dL, gR, dR, (ql["x"], ql["y"], ql["radius"], lvl), (qr["x"], qr["y"], qr["radius"], lvl), qdesc, l2r, r2l,
+        taken0, marks, 0.8)
+    kpq_p, taken_p, n_p, n_exit = R.search_by_projection_two_cameras(gL, kL, dL, gR, kR, dR, ql, qr, qdesc, l2r, r2l,
+                                                                     taken0, marks, 0.8)
+    kpq_w, _, n_w, _ = R.search_by_projection_two_cameras(gL, kL, dL, gR, kR, dR, ql, qr, qdesc, l2r, r2l, taken0, marks,
+                                                          0.8, skip_right_after_left_ratio_failure=False)
+    fL, fR = A.FrameFeatures(kL, dL, None, BOUNDS), A.FrameFeatures(kR, dR, None, BOUNDS)
+    taken = taken0.copy()
+    kpq, n = A.ORBmatcher(0.8).SearchByProjectionStereoIn(fL, fR, ql, qr, qdesc, taken, l2r, r2l, marks)
+    assert n_exit >= 150
+    assert n == n_o == n_p
+    assert np.array_equal(kpq, kpq_o) and np.array_equal(kpq, kpq_p)
+    assert np.array_equal(taken, taken_o) and np.array_equal(taken, taken_p)
+    assert n_w >= n + 100 and not np.array_equal(kpq_w, kpq)
+
+
 def test_search_by_projection_one_camera_equals_existing_entry_point(oracle, fisheye_frame):
     """right = NULL and all marks 1 is the mono loop of orbx_frame_search_by_projection."""
     A = _gpu()
@@ -260,18 +293,28 @@ def test_search_for_triangulation_camera_pairs(oracle, coarse, check_ori):
     cam_params = np.stack([KB_L, KB_R, KB_L, KB_R])
     sig2 = (SF * SF).astype(np.float32)
     args = (k1, d1, f1, None, nl1, fv1[0], fv1[1], k2, d2, f2, None, nl2, fv2[0], fv2[1])
-    out_o, n_o = oracle.search_for_triangulation_cameras(*args, cam_types, cam_params, poses, (0.0, 0.0), SF, sig2, sig2,
-                                                         False, coarse, check_ori)
+    out_o, n_o, margin = oracle.search_for_triangulation_cameras(*args, cam_types, cam_params, poses, (0.0, 0.0), SF, sig2,
+                                                                 sig2, False, coarse, check_ori, with_margin=True)
     out, n = A.ORBmatcher(0.6, check_ori).SearchForTriangulationCameras(
         k1, d1, f1, None, nl1, fv1, k2, d2, f2, None, nl2, fv2, cam_types, cam_params, poses, (0.0, 0.0), SF, sig2, sig2,
         False, coarse)
-    assert n == n_o and np.array_equal(out, out_o)
+    # The oracle's gates are an independent binary64 restatement (oracle/camera_oracle.cpp); a keypoint's outcome may
+    # differ from it only if one of the gates evaluated for it lay inside the rounding band of its threshold
+    # (margin < 1; one keypoint of this fixture, at 0.94 of the band).
+    in_band = margin < 1
+    print(f"triangulation gates: {int(in_band.sum())} of {len(margin)} keypoints had a gate inside its rounding band")
+    differ = out != out_o
+    assert not (differ & ~in_band).any(), "a match differs although no gate of that keypoint was within rounding of its threshold"
+    if not check_ori:
+        assert n - int(differ.sum()) <= n_o <= n + int(differ.sum())
+    if not differ.any():
+        assert n == n_o
     # the same search on keyframes whose (combined) descriptor arrays are resident on the device
     from orb_slam3_amd.matcher import triangulation_geometry
     kf1, kf2 = A.FrameFeatures(k1, d1, None, BOUNDS), A.FrameFeatures(k2, d2, None, BOUNDS)
     geom = triangulation_geometry(nl1, nl2, cam_types, cam_params, poses, (0.0, 0.0), SF, sig2, sig2)
     out_f, n_f = A.ORBmatcher(0.6, check_ori).SearchForTriangulationIn(kf1, f1, fv1, kf2, f2, fv2, geom, False, coarse)
-    assert n_f == n_o and np.array_equal(out_f, out_o)
+    assert n_f == n and np.array_equal(out_f, out)
     m = np.nonzero(out >= 0)[0]
     assert len(m) > 60
     # all four camera pairs occur among the matches
@@ -317,10 +360,12 @@ def test_search_for_triangulation_cameras_single_camera_equals_existing_entry_po
     m = A.ORBmatcher(0.6, False)
     out, nm = m.SearchForTriangulationCameras(k1, d1, free, None, -1, fv, k2, d2, free, None, -1, fv, [0, 0, 0, 0],
                                               np.stack([pin] * 4), poses, ep, SF, sig2, sig2)
-    out_o, n_o = oracle.search_for_triangulation_cameras(k1, d1, free, None, -1, fv[0], fv[1], k2, d2, free, None, -1,
-                                                         fv[0], fv[1], [0, 0, 0, 0], np.stack([pin] * 4), poses, ep, SF,
-                                                         sig2, sig2, False, False, False)
-    assert nm == n_o and np.array_equal(out, out_o)
+    out_o, n_o, margin = oracle.search_for_triangulation_cameras(k1, d1, free, None, -1, fv[0], fv[1], k2, d2, free, None, -1,
+                                                                 fv[0], fv[1], [0, 0, 0, 0], np.stack([pin] * 4), poses, ep,
+                                                                 SF, sig2, sig2, False, False, False, with_margin=True)
+    differ = out != out_o
+    assert not (differ & ~(margin < 1)).any()           # Pinhole::epipolarConstrain against the binary64 checker
+    assert differ.sum() <= 3 and abs(nm - n_o) <= differ.sum()
     # F12 = K1^-T [t12]x R12 K2^-1 in double, rounded: the existing entry point agrees wherever the line distance
     # is not within rounding of its threshold
     tx = np.array([[0, -t12[2], t12[1]], [t12[2], 0, -t12[0]], [-t12[1], t12[0], 0]], np.float64)
@@ -373,14 +418,24 @@ def test_compute_stereo_fisheye_matches(oracle):
     dR_full = np.concatenate([synth.random_descriptors(mono_r, 34), dR_all])
     dR_full[mono_r + 5] = dR_full[mono_r + 9]                   # two equal right descriptors: the lower index wins or the ratio fails
     sigma2 = (np.float32(1.2) ** (2 * np.arange(8))).astype(np.float32)
-    want = oracle.stereo_fisheye_matches(kL_full, dL_full, mono_l, kR_full, dR_full, mono_r, cam, cam2, R, t, sigma2)
+    want = oracle.stereo_fisheye_matches(kL_full, dL_full, mono_l, kR_full, dR_full, mono_r, cam, cam2, R, t, sigma2,
+                                         with_margin=True)
     c1, c2 = CameraModel(1, (C.c_float * 8)(*cam)), CameraModel(1, (C.c_float * 8)(*cam2))
     got = compute_stereo_fisheye_matches(kL_full, dL_full, mono_l, kR_full, dR_full, mono_r, c1, c2, R, t, sigma2)
-    assert got[4] == want[4] and 200 < got[4] < n
-    for g, w in zip(got[:3], want[:3]):
-        assert np.array_equal(g, w)
-    ok = got[0] >= 0
-    assert np.array_equal(got[3][ok], want[3][ok])
+    # The oracle triangulates in binary64 with its own null-vector routine (oracle/camera_oracle.cpp): the match
+    # tables are identical wherever no gate lay within rounding of its threshold (margin >= 1), depths and points
+    # agree to 5e-3 relative (binary32 SVD in the library, as in the reference).
+    in_band = want[5] < 1
+    print(f"fisheye stereo: {int(in_band.sum())} of {int((want[5] < 1e299).sum())} triangulated pairs inside a rounding band")
+    differ = got[0] != want[0]
+    assert not (differ & ~in_band).any()
+    assert abs(got[4] - want[4]) <= differ.sum() and 200 < got[4] < n
+    if not differ.any():
+        assert np.array_equal(got[1], want[1])
+    ok = (got[0] >= 0) & ~differ
+    assert np.allclose(got[2][ok], want[2][ok], rtol=5e-3)
+    assert np.allclose(got[3][ok], want[3][ok], rtol=5e-3, atol=5e-3)
+    assert (got[2][~(got[0] >= 0)] == -1).all()
     assert (got[0][:mono_l] == -1).all() and (got[1][:mono_r] == -1).all()
     # the triangulated points are the scene's points (camera-1 coordinates) up to the pixel noise
     src = np.nonzero(ok)[0] - mono_l

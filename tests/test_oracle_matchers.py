@@ -1,7 +1,13 @@
 """Hand-derivable known answers for the oracle's restatements of the order-dependent ORBmatcher
 loops (the reference has no tests for them): tie rules, the "taken" rule, thresholds, the
 rotation histogram with its 10 % rule, and the replace-on-equal rule of SearchForTriangulation."""
+import os
+import sys
+
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from orb_slam3_amd import synth  # noqa: E402
 
 BOUNDS = (0.0, 640.0, 0.0, 480.0)
 
@@ -113,3 +119,31 @@ def test_initialization_reassigns_to_better_match(oracle):
     m, prev2, n = O.search_for_initialization(k1, d1, g2, d2, prev, 20, 0.9, False)
     assert n == 1 and list(m) == [-1, 0]         # keypoint 0 matched first (10), then lost it to keypoint 1 (3 < 10)
     assert list(prev2[1]) == [102, 100] and list(prev2[0]) == [100, 100]
+
+
+def test_two_camera_projection_left_ratio_failure_ends_the_map_point(oracle):
+    """ORBmatcher.cc:125-126: the `continue` after a failed left ratio test leaves the map-point loop, so the
+    right-camera pass (:146-213) is skipped for that point.  The oracle is compared with an independent Python
+    transcription of :42-216, on a fixture where that happens for 200 map points whose right window holds a clear
+    match; the transcription with the exit misread (right pass still run) must differ."""
+    import replay_two_cameras as R
+    kL, dL, kR, dR, ql, qr, qdesc, l2r, r2l, half = R.ambiguous_left_fixture(3, 400, synth.KP_DTYPE, synth.QUERY_DTYPE)
+    bounds = (0.0, 512.0, 0.0, 512.0)
+    gL, gR = oracle.Grid(kL, *bounds), oracle.Grid(kR, *bounds)
+    rng = np.random.default_rng(9)
+    taken0 = (rng.random(len(kL) + len(kR)) < 0.05).astype(np.uint8)
+    marks = (rng.random(len(ql)) < 0.9).astype(np.uint8)
+    lvl = ql["max_level"].astype(np.int32)
+    kpq_o, taken_o, n_o = oracle.search_by_projection_stereo(
+        gL, dL, gR, dR, (ql["x"], ql["y"], ql["radius"], lvl), (qr["x"], qr["y"], qr["radius"], lvl), qdesc, l2r, r2l,
+        taken0, marks, 0.8)
+    kpq, taken, n, n_exit = R.search_by_projection_two_cameras(gL, kL, dL, gR, kR, dR, ql, qr, qdesc, l2r, r2l, taken0,
+                                                               marks, 0.8)
+    assert n_exit >= 150                                   # map points that leave at :126 with a right candidate waiting
+    assert n == n_o and np.array_equal(kpq, kpq_o) and np.array_equal(taken, taken_o)
+    kpq_w, taken_w, n_w, _ = R.search_by_projection_two_cameras(gL, kL, dL, gR, kR, dR, ql, qr, qdesc, l2r, r2l, taken0,
+                                                                marks, 0.8, skip_right_after_left_ratio_failure=False)
+    assert n_w >= n + 100 and not np.array_equal(kpq_w, kpq)
+    # the skipped points own nothing in either camera
+    owners = set(kpq[kpq >= 0].tolist())
+    assert len(owners) < len(ql) - 150
