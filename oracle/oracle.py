@@ -520,8 +520,8 @@ def search_for_triangulation(kps1, desc1, free1, ur1, idx1, off1, kps2, desc2, f
     n = lib().orc_search_for_triangulation(_p(kps1), _p(desc1), _p(a[0]), _p(a[1]), len(kps1), _p(a[2]), _p(a[3]),
                                            _p(kps2), _p(desc2), _p(b[0]), _p(b[1]), len(kps2), _p(b[2]), _p(b[3]),
                                            len(a[3]) - 1, _p(F), float(ep[0]), float(ep[1]), _p(sf), _p(sg),
-                                           int(only_stereo), int(coarse), int(check_ori), _p(out), _p(margin))
-    return (out, n, margin) if with_margin else (out, n)
+                                           int(only_stereo), int(coarse), int(check_ori), _p(out))
+    return out, n
 
 
 def bow_transform(child_off, child_idx, node_desc, word_id, weight, depth, desc, levelsup):
