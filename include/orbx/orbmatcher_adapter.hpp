@@ -153,11 +153,13 @@ int search_by_bow_keyframes(KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPoi
     vpMatches12.assign(vpMapPoints1.size(), static_cast<MapPointT*>(nullptr));
     Matcher::NodeLists a, b;
     shared_nodes(pKF1->mFeatVec, pKF2->mFeatVec, a, b);
-    // a fisheye keyframe's feature vector also lists right-camera features; :868 skips those of keyframe 1
-    const size_t nUn1 = pKF1->mvKeysUn.size();
+    // a fisheye keyframe's feature vector also lists right-camera features; :859-862 skips those of keyframe 1 and
+    // :880-883 those of keyframe 2 (indices at or beyond mvKeysUn.size() when NLeft != -1)
+    const size_t nUn1 = pKF1->NLeft != -1 ? pKF1->mvKeysUn.size() : vpMapPoints1.size();
+    const size_t nUn2 = pKF2->NLeft != -1 ? pKF2->mvKeysUn.size() : vpMapPoints2.size();
     std::vector<uint8_t> v1(vpMapPoints1.size(), 0), v2(vpMapPoints2.size(), 0);
     for (size_t i = 0; i < v1.size(); ++i) v1[i] = (i < nUn1 && vpMapPoints1[i] && !vpMapPoints1[i]->isBad()) ? 1 : 0;
-    for (size_t i = 0; i < v2.size(); ++i) v2[i] = (vpMapPoints2[i] && !vpMapPoints2[i]->isBad()) ? 1 : 0;
+    for (size_t i = 0; i < v2.size(); ++i) v2[i] = (i < nUn2 && vpMapPoints2[i] && !vpMapPoints2[i]->isBad()) ? 1 : 0;
     std::vector<int> m12(vpMapPoints1.size(), -1);
     int n = 0;
     check(orbx_frame_search_by_bow_keyframes(f1.handle(), v1.data(), a.idx.data(), a.off.data(), f2.handle(), v2.data(),
@@ -461,7 +463,8 @@ public:
         std::vector<int> src;
         std::vector<orbx_query> qs;
         std::vector<uint8_t> qd;
-        Sim3Queries(pKF, Scw, vpPoints, std::set<MapPoint*>(vpMatched.begin(), vpMatched.end()), (float)th, qs, qd, src);
+        // this overload projects with fx, fy, cx, cy itself (:621-626) instead of calling the camera model
+        Sim3Queries(pKF, Scw, vpPoints, std::set<MapPoint*>(vpMatched.begin(), vpMatched.end()), (float)th, qs, qd, src, true);
         auto Kh = orbx::adapt::features_of(*pKF, pKF->NLeft == -1 ? 3 : 0);
         std::vector<uint8_t> taken = orbx::adapt::taken_non_null(vpMatched);
         taken.resize(Kh->size());
@@ -707,9 +710,12 @@ public:
     }
 
 protected:
-    // The geometric preamble shared by the Sim3 projection searches and Fuse (:485-538, :1418-1473).
+    // The geometric preamble shared by the Sim3 projection searches and Fuse (:485-538, :591-650, :1418-1473).
+    // inlinePinhole: the projection written out as in :621-626 (u = fx * (x * invz) + cx), which rounds differently
+    // from Pinhole::project's fx * x / z + cx and ignores a fisheye model.
     void Sim3Queries(KeyFrame* pKF, Sophus::Sim3f& Scw, const std::vector<MapPoint*>& vpPoints, const std::set<MapPoint*>& already,
-                     float th, std::vector<orbx_query>& qs, std::vector<uint8_t>& qd, std::vector<int>& src) {
+                     float th, std::vector<orbx_query>& qs, std::vector<uint8_t>& qd, std::vector<int>& src,
+                     bool inlinePinhole = false) {
         Sophus::SE3f Tcw = Sophus::SE3f(Scw.rotationMatrix(), Scw.translation() / Scw.scale());
         Eigen::Vector3f Ow = Tcw.inverse().translation();
         for (int iMP = 0, iend = vpPoints.size(); iMP < iend; iMP++) {
@@ -718,7 +724,15 @@ protected:
             Eigen::Vector3f p3Dw = pMP->GetWorldPos();
             Eigen::Vector3f p3Dc = Tcw * p3Dw;
             if (p3Dc(2) < 0.0) continue;
-            const Eigen::Vector2f uv = pKF->mpCamera->project(p3Dc);
+            Eigen::Vector2f uv;
+            if (inlinePinhole) {
+                const float invz = 1 / p3Dc(2);
+                const float x = p3Dc(0) * invz, y = p3Dc(1) * invz;
+                uv(0) = pKF->fx * x + pKF->cx;
+                uv(1) = pKF->fy * y + pKF->cy;
+            } else {
+                uv = pKF->mpCamera->project(p3Dc);
+            }
             if (!pKF->IsInImage(uv(0), uv(1))) continue;
             Eigen::Vector3f PO = p3Dw - Ow;
             const float dist = PO.norm();
