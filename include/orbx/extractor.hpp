@@ -209,8 +209,9 @@ public:
         _keypoints.resize(n);
         if (n == 0) _descriptors.release();
         else { _descriptors.create(n, 32, CV_8U); std::memcpy(_descriptors.getMat().data, desc_.data, (size_t)n * 32); }
-        // Frame::ComputeStereoMatches reads mvImagePyramid in the reference; with orbx_stereo_match it does not, so the
-        // eight level images are only brought back to the host on request
+        // Frame::ComputeStereoMatches of the reference indexes mvImagePyramid[kpL.octave] (Frame.cc:970, :1060-1075), so
+        // the drop-in class fills it by default; an integration that routes stereo matching to orbx_stereo_match
+        // (which reads the device copy) sets keepPyramid = false and saves the eight downloads per frame
         if (keepPyramid) {
             impl_.fetch_pyramid();
             mvImagePyramid.resize(impl_.mvImagePyramid.size());
@@ -221,7 +222,7 @@ public:
         }
         return mono;
     }
-    bool keepPyramid = false;
+    bool keepPyramid = true;
     int GetLevels() { return impl_.GetLevels(); }
     float GetScaleFactor() { return impl_.GetScaleFactor(); }
     std::vector<float> GetScaleFactors() { return impl_.GetScaleFactors(); }
