@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """Benchmark of the ORB front-end hot path on MI355X.
 
-A step = one pass of the hot path over one batch of synthetic EuRoC-shaped stereo pairs that
-are already resident in HBM: left + right ORBextractor::operator() (752x480, 1000 features,
-8 levels x 1.2, FAST 20/7) followed by Frame::ComputeStereoMatches -- the reference's EuRoC stereo configuration
-(Examples/Stereo/EuRoC.yaml; nFeatures = 1000 as in the metric's name, the yaml itself sets 1200).
+A step = one pass of the hot path over a stream of --batches-per-step (32) batches of 128 synthetic EuRoC-shaped
+stereo pairs that are already resident in HBM: per batch left + right ORBextractor::operator() (752x480, 1000
+features, 8 levels x 1.2, FAST 20/7) followed by Frame::ComputeStereoMatches -- the reference's EuRoC stereo
+configuration (Examples/Stereo/EuRoC.yaml; nFeatures = 1000 as in the metric's name, the yaml itself sets 1200).
+32 batches make a step about 28 ms of GPU work, so that the K = 20 timed steps last more than half a second.
 value = ORB frames (images) extracted per second, summed over all ranks.
-Consecutive steps are pipelined: they alternate between two sets of extractor handles, result arrays and stream
-pairs, so step i + 1 begins its extraction while step i is still describing and matching (frames arrive as a
-stream; nothing of a step is skipped, and the timed region ends with a device synchronisation).  The same K steps
-with a synchronisation after each one are timed as well ("value_one_step_at_a_time").
+Consecutive batches are pipelined: they alternate between two sets of extractor handles, result arrays and stream
+pairs, so batch i + 1 begins its extraction while batch i is still being described and matched (frames arrive as a
+stream; nothing of a batch is skipped, and the timed region ends with a device synchronisation).  The same batches
+with a synchronisation after each one are timed as well ("value_one_batch_at_a_time").
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): frames are sharded over the ranks,
 no data-path collective (weak scaling); the timing is barrier-bracketed and the max over ranks.
@@ -65,6 +66,13 @@ def cpu_baseline(n_pairs):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     from orb_slam3_amd import synth
+    # the oracle rebuilt for this host (-O3 -march=native -ffp-contract=off; tests/test_oracle_builds.py checks that it
+    # gives the portable build's results); the portable build if that fails
+    try:
+        flags = O.use_build("native")
+    except Exception as e:                                    # no compiler on this host
+        print(f"cpu_baseline: native oracle build failed ({e}); timing the portable build", file=sys.stderr)
+        flags = O.use_build("portable")
     pairs = [synth.stereo_pair(W, H, 9000 + i) for i in range(n_pairs)]
 
     def one_pair(L, R):
@@ -103,7 +111,7 @@ def cpu_baseline(n_pairs):
         with ThreadPoolExecutor(cores) as ex:
             list(ex.map(lambda _: O.knn2(q, t, fast), range(cores)))
         rates[name + "_all_cores"] = cores * 64 * 200_000 / (time.perf_counter() - a)
-    return {"value": 2 * n_pairs / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+    return {"value": 2 * n_pairs / dt, "unit": "frames/s", "cores": 1, "kind": "port", "flags": "g++ " + flags,
             "sample": f"{n_pairs} synthetic 752x480 stereo pairs, CPU oracle: 2 extractions + stereo match per pair",
             "extract_ms_per_frame": 1e3 * t_ext / (2 * n_pairs),
             "all_cores": {"value": 2 * len(work) / dt_all, "unit": "frames/s", "cores": cores,
@@ -143,7 +151,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="stereo pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="stereo pairs per batch per GPU")
+    ap.add_argument("--batches-per-step", type=int, default=32, help="pipelined batches that make one step")
     ap.add_argument("--cpu-pairs", type=int, default=16, help="stereo pairs of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-hamming", action="store_true")
     ap.add_argument("--no-1080p", action="store_true")
@@ -237,7 +246,18 @@ def main():
             sets[k][name], overlap4 = pick_concurrent_stream(torch, dev, chosen)
             chosen.append(sets[k][name])
 
+    BPS = max(1, args.batches_per_step)
+
     def step(i=0):
+        """One step: BPS pipelined batches.  Returns the result arrays of the step's last batch on set 0."""
+        r0 = None
+        for j in range(BPS):
+            r = batch_step(i * BPS + j)
+            if (i * BPS + j) % NSETS == 0:
+                r0 = r
+        return r0
+
+    def batch_step(i=0):
         S = sets[i % NSETS]
         a, b = S["sL"], S["sR"]
         b.wait_stream(a)             # the set's previous stereo match (on a) read the right handle's pyramid and arrays
@@ -258,24 +278,29 @@ def main():
         if world > 1:
             dist.barrier()
 
-    for w in range(NSETS * max(args.warmup, 1)):
-        step(w)
+    for w in range(2 * NSETS):
+        batch_step(w)
         torch.cuda.synchronize()
         check_status()                    # a capacity overflow regrows the buffers during warm-up
+    for w in range(args.warmup):
+        step(w)
     barrier(); torch.cuda.synchronize()
+    check_status()
     t0 = time.perf_counter()
     for i in range(args.steps):
         r = step(i)
-        if i % NSETS == 0:
+        if r is not None:
             ur, depth = r                 # set 0's result arrays (checked below against set 0's counts)
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     check_status()
-    # the same K steps one at a time (a device synchronisation after each): what one step costs without its neighbours
+    # the same kind of batch one at a time (a device synchronisation after each): what a batch costs without its
+    # neighbours; K * BPS / 4 batches
+    n_serial = max(NSETS, args.steps * BPS // 4)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    for i in range(n_serial):
+        batch_step(i)
         torch.cuda.synchronize()
     dt_serial = time.perf_counter() - t0
     if world > 1:
@@ -289,8 +314,9 @@ def main():
     exL.set_timing(True); exR.set_timing(True)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step(0)
+    n_events = 2 * args.steps
+    for _ in range(n_events):
+        batch_step(0)
         torch.cuda.synchronize()
     dt_events = time.perf_counter() - t1
     tL, nL = exL.get_timing()
@@ -301,14 +327,15 @@ def main():
     # beside it a span is the kernel's duration (what rocprofv3 reports for these launches).
     exL.set_timing(True)
     torch.cuda.synchronize()
-    for _ in range(args.steps):
+    for _ in range(2 * args.steps):
         with torch.cuda.stream(sL):
             exL.extract_batch_device(dL, (0, 0), out=outL)
     torch.cuda.synchronize()
     tA, nA = exL.get_timing()
     exL.set_timing(False)
     stage_ms = {k: tA[k] / max(nA, 1) for k in tA}
-    frames_per_step = 2 * B * world
+    frames_per_batch = 2 * B * world
+    frames_per_step = frames_per_batch * BPS
     value = frames_per_step * args.steps / dt
     counts = outL[2].cpu().numpy()
     n_kp = float(counts[:, 0].mean())
@@ -363,7 +390,7 @@ def main():
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "EuRoC stereo (stereo_euroc): left+right extraction + "
                                "ComputeStereoMatches, 752x480, nFeatures=1000, 8 levels x1.2, FAST 20/7",
-                   "pairs_per_step_per_gpu": B, "frames_per_step": frames_per_step,
+                   "pairs_per_batch_per_gpu": B, "batches_per_step": BPS, "frames_per_step": frames_per_step,
                    "keypoints_per_frame": n_kp, "stereo_matches_frame0": n_match, "parallelism": f"frames sharded x{world}"},
         "roofline": {"bound": "hbm", "kernel": "k_fast", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -381,13 +408,15 @@ def main():
         "stage_ms_per_launch_in_situ": stage_ms_in_situ,
         "stage_timing": {"how": "stage_ms_per_launch: the left extractor alone; ..._in_situ: second pass of the same K "
                                 "two-stream steps with hipEvents between the kernels",
-                         "ms_per_step_with_events": 1e3 * dt_events / args.steps},
+                         "ms_per_batch_with_events": 1e3 * dt_events / n_events},
         "stream_overlap_ratio": overlap,
         "stream_overlap_ratio_4": overlap4,
-        "pipelining": "consecutive steps alternate between two sets of extractor handles and streams; step i + 1 "
-                      "starts while step i is still describing and matching",
-        "ms_per_step_one_at_a_time": 1e3 * dt_serial / args.steps,
-        "value_one_step_at_a_time": frames_per_step * args.steps / dt_serial,
+        "pipelining": "consecutive batches alternate between two sets of extractor handles and streams; batch i + 1 "
+                      "starts while batch i is still being described and matched",
+        "timed_region_s": dt,
+        "ms_per_batch": 1e3 * dt / (args.steps * BPS),
+        "ms_per_batch_one_at_a_time": 1e3 * dt_serial / n_serial,
+        "value_one_batch_at_a_time": frames_per_batch * n_serial / dt_serial,
     }
 
     if valu is not None:
@@ -422,9 +451,10 @@ def main():
                 exs[k].extract_batch_device(dF[k], (0, 0), out=outs[k])
             torch.cuda.synchronize()
             exs[0].status(); exs[1].status()
-        launches = max(2, (1024 // HB) & ~1)
+        # 27 x 1024 frames per two-stream measurement: more than half a second of GPU work
+        launches = max(2, (27 * 1024 // HB) & ~1)
 
-        def run(n_streams):
+        def run(n_streams, launches):
             barrier(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(launches):
@@ -439,8 +469,9 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 d = float(t.item())
             return d
-        dth1 = run(1)
-        dth = run(2)
+        launches1 = max(2, (launches // 4) & ~1)
+        dth1 = run(1, launches1)
+        dth = run(2, launches)
         exH.set_timing(True)
         for _ in range(4):
             with torch.cuda.stream(sA):
@@ -456,7 +487,8 @@ def main():
             "workload": f"synthetic 1920x1080, nFeatures=5000, 8 levels x1.2, FAST 20/7: {launches} launches of {HB} frames per GPU "
                         f"({2 * HB} distinct frames), two extractor handles alternating on two streams, inputs resident in HBM",
             "frames_per_s": fpsH, "ms_per_frame": 1e3 * dth / (launches * HB), "keypoints_per_frame": nkH,
-            "one_stream_frames_per_s": launches * HB * world / dth1,
+            "one_stream_frames_per_s": launches1 * HB * world / dth1,
+            "timed_region_s": dth,
             "stream_overlap_ratio": overlapH,
             "bytes_per_frame": bytesH,
             "path_roofline": {"bound": "hbm", "achieved": fpsH / world * bytesH / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -487,7 +519,7 @@ def main():
                 return A.knn2_merge_device(gathered.view(world, NQ_MAP, 4))
             return p
         search(); torch.cuda.synchronize(); barrier()
-        iters = 5
+        iters = 24
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
@@ -502,9 +534,39 @@ def main():
             th = float(t.item())
         per = th / iters
         pairs_s = NQ_MAP * NT_MAP / per
+        # outside the timed region: the result of the last search is checked by recomputing every reported distance
+        # from the rows it names (those of this rank's shard) and, for four queries, by a full brute-force search
+        lut = torch.tensor([bin(v).count("1") for v in range(256)], dtype=torch.uint8, device=dev)
+        resl = res.to(torch.int64)
+        checked = 0
+        for col in (0, 2):
+            idx, dd = resl[:, col], resl[:, col + 1]
+            mine = (idx >= base) & (idx < base + n_local)
+            rows = dt_map[(idx[mine] - base)]
+            d = lut[(rows ^ dq[mine]).to(torch.int64)].sum(1, dtype=torch.int64)
+            assert bool((d == dd[mine]).all()), "kNN: a reported distance differs from the recomputed one"
+            checked += int(mine.sum().item())
+        assert bool((resl[:, 1] <= resl[:, 3]).all())
+        brute_ok = True
+        if world == 1:
+            for qi in (0, 1, NQ_MAP // 2, NQ_MAP - 1):
+                d = torch.zeros(n_local, dtype=torch.int32, device=dev)
+                for c0 in range(0, n_local, 2_000_000):
+                    blk = dt_map[c0:c0 + 2_000_000]
+                    d[c0:c0 + len(blk)] = lut[(blk ^ dq[qi]).to(torch.int64)].sum(1, dtype=torch.int32)
+                d0 = int(d.min().item())
+                i0 = int((d == d0).nonzero()[0].item())                  # lowest index among equals
+                d[i0] = 1 << 20
+                d1 = int(d.min().item())
+                i1 = int((d == d1).nonzero()[0].item())
+                brute_ok = brute_ok and [i0, d0, i1, d1] == [int(v) for v in resl[qi].tolist()]
+            assert brute_ok, "kNN: result differs from a brute-force search"
         out["hamming"] = {"workload": f"{NQ_MAP} queries x {NT_MAP} map descriptors (large-map brute-force search), "
                                       f"map sharded x{world}, top-2 all-gather + merge",
                           "matches_per_s": NQ_MAP / per, "pairs_per_s": pairs_s, "ms_per_search": 1e3 * per,
+                          "searches_timed": iters, "timed_region_s": th,
+                          "result_check": {"distances_recomputed": checked, "brute_force_queries": 4 if world == 1 else 0,
+                                           "ok": True},
                           "scaling": "strong",
                           "roofline": {"bound": "valu-u32", "ops_per_pair": 16, "achieved": pairs_s * 16 / 1e12,
                                        "peak": VALU_XOR_BCNT_MEASURED * world / 1e12, "unit": "Tops/s",

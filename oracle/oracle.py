@@ -26,12 +26,36 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+NATIVE_FLAGS = "-O3 -march=native -ffp-contract=off -fno-fast-math"
+PORTABLE_FLAGS = "-O2 -ffp-contract=off -fno-fast-math"
+build_flags = PORTABLE_FLAGS
+
+
+def use_build(kind: str) -> str:
+    """Switch this module to another build of the same sources: "native" (-O3 -march=native, built on this machine:
+    what the bench's CPU baseline times), "asan" (AddressSanitizer + UBSan; the process must have the sanitizer
+    runtime preloaded) or "portable" (the default).  Returns the flags of the build now in use."""
+    global _SO, _lib, build_flags
+    if kind == "portable":
+        so, flags = os.path.join(_HERE, "_build", "liborb_oracle.so"), PORTABLE_FLAGS
+        build()
+    else:
+        so = os.path.join(_HERE, "_build", f"liborb_oracle_{kind}.so")
+        flags = NATIVE_FLAGS if kind == "native" else "-O1 -fsanitize=address,undefined"
+        subprocess.check_call(["make", "-C", _HERE, "-s", kind])
+    _SO, _lib, build_flags = so, None, flags
+    return flags
+
+
 _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
+        kind = os.environ.get("ORB_ORACLE_BUILD", "")          # tests/test_sanitizers.py: run the tests on the asan build
+        if kind in ("native", "asan") and not _SO.endswith(f"_{kind}.so"):
+            use_build(kind)
         if not os.path.exists(_SO):
             build()
         L = C.CDLL(_SO)

@@ -126,7 +126,12 @@ extern "C" orbx_status orbx_archive_read_matrix(const uint8_t* buf, size_t len, 
     r.b8();                                         // `continuous` only decides how the writer split its make_array calls
     ORBX_REQUIRE(r.ok, "truncated or malformed matrix header");
     ORBX_REQUIRE(c >= 0 && rw >= 0 && type >= 0 && type < 512, "implausible matrix header (%d x %d, type %d)", rw, c, type);
-    const size_t bytes = (size_t)c * (size_t)rw * elem_size_of_cv_type(type);
+    // the payload has to fit into what is left of the image (a text archive spends at least two characters per byte);
+    // checked by division so that a forged header cannot wrap the byte count
+    const size_t elem = elem_size_of_cv_type(type), left = (len - r.pos) / (r.text ? 2 : 1);
+    ORBX_REQUIRE(c == 0 || rw == 0 || ((size_t)c <= left / elem && (size_t)rw <= left / elem / (size_t)c),
+                 "matrix header promises more than the archive holds (%d x %d, type %d)", rw, c, type);
+    const size_t bytes = (size_t)c * (size_t)rw * elem;
     *rows = rw; *cols = c; *cv_type = type;
     if (!out) {                                     // size query: skip the payload
         if (!r.text) { ORBX_REQUIRE(r.pos + bytes <= len, "truncated matrix payload"); r.pos += bytes; }
