@@ -175,6 +175,9 @@ def main():
 
     import orb_slam3_amd as A
     from orb_slam3_amd import synth
+    # the interpreter's first full garbage collection (35-45 ms over what the imports leave behind) happens here, not
+    # inside a timed call (it used to hit one extraction call per process: profiles/r03_slow_call_gc_probe.txt)
+    A.settle_interpreter()
 
     host_path = None
     # --- the host entry points: pageable image in, keypoints / descriptors in host memory out (PCIe inclusive).
@@ -184,8 +187,8 @@ def main():
         ex1 = A.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, device=local)
         for _ in range(50):
             ex1(imgs[0], (0, 0))
-        # five windows of 100 calls: a call is ~0.16 ms of light GPU work, and on some runs the first windows are
-        # three times slower (the device has not left its idle clocks yet), so the windows are reported one by one
+        # five windows of 100 calls from a cold handle, reported one by one (no window may be slower than 1.3 x the
+        # median: the 35-45 ms pause that one window used to contain was the interpreter's garbage collector)
         windows = []
         for _ in range(5):
             t0 = time.perf_counter()
@@ -193,18 +196,38 @@ def main():
                 ex1(imgs[i % 8], (0, 0))
             windows.append(100 / (time.perf_counter() - t0))
         single = float(np.median(windows))
-        exb = A.ORBextractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, W, H, max_batch=64, device=local)
-        batch = [imgs[i % 8] for i in range(64)]
-        exb.extract_batch(batch, (0, 0))
-        t0 = time.perf_counter()
-        for _ in range(4):
-            exb.extract_batch(batch, (0, 0))
-        batched = 4 * 64 / (time.perf_counter() - t0)
-        host_path = {"what": "orbx_extract / orbx_extract_batch through the ctypes mirror: pageable 752x480 images in, "
-                                    "keypoints and descriptors in host memory out (H2D + kernels + D2H + synchronisation)",
-                            "orbx_extract_frames_per_s": single, "orbx_extract_windows_frames_per_s": windows,
-                            "orbx_extract_batch64_frames_per_s": batched}
-        del ex1, exb
+        def batched_rate(w, h, nfeat, nb, reps, seed0):
+            """orbx_extract_batch of nb frames per call (a pipeline of upload chunks), pageable images in, host arrays out."""
+            src = [synth.scene(w, h, seed0 + i, n_prims=400 if w < 1000 else 1500) for i in range(8)]
+            exb = A.ORBextractor(nfeat, SCALE, NLEVELS, INI_TH, MIN_TH, w, h, max_batch=nb, device=local)
+            batch = [src[i % 8] for i in range(nb)]
+            exb.extract_batch(batch, (0, 0), copy=False)
+            exb.extract_batch(batch, (0, 0), copy=False)
+            t0 = time.perf_counter()
+            nk = 0
+            for _ in range(reps):
+                out = exb.extract_batch(batch, (0, 0), copy=False)
+                nk += sum(len(o[0]) for o in out)
+            dt = time.perf_counter() - t0
+            fps = reps * nb / dt
+            # what crosses the link per frame: the image in, capacity x 60 bytes of result rows and the counts out
+            link = (w * h + exb.max_keypoints * 60 + 8) * fps
+            del exb
+            return fps, link, nk / (reps * nb)
+        b64, _, _ = batched_rate(W, H, NFEAT, 64, 8, 40)
+        b256, link256, nk256 = batched_rate(W, H, NFEAT, 256, 6, 40)
+        bhd, linkhd, nkhd = batched_rate(1920, 1080, 5000, 64, 4, 70)
+        host_path = {"what": "orbx_extract / orbx_extract_batch through the ctypes mirror: pageable images in, keypoints and "
+                             "descriptors in host memory out (staging copy + H2D + kernels + D2H + copy out + synchronisation); "
+                             "batches of three upload chunks or more run as a pipeline on three streams with the host copies "
+                             "on four threads",
+                     "orbx_extract_frames_per_s": single, "orbx_extract_windows_frames_per_s": windows,
+                     "orbx_extract_batch64_frames_per_s": b64,
+                     "orbx_extract_batch256_frames_per_s": b256, "orbx_extract_batch256_pcie_bytes_per_s": link256,
+                     "orbx_extract_batch256_keypoints_per_frame": nk256,
+                     "orbx_extract_batch_1080p_frames_per_s": bhd, "orbx_extract_batch_1080p_pcie_bytes_per_s": linkhd,
+                     "orbx_extract_batch_1080p_keypoints_per_frame": nkhd}
+        del ex1
 
     B = args.batch
     # B distinct stereo pairs per rank (seeded)

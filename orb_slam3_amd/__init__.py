@@ -9,3 +9,14 @@ from .matcher import (Camera, FrameFeatures, ORBmatcher, bucket_allpairs, bucket
                       fisheye_ratio_matches, knn2_merge_device, knn_match2, knn_match2_device, window_candidates)
 from .vocabulary import Vocabulary, shared_nodes  # noqa: F401,E402
 from .staging import InputStager  # noqa: F401,E402
+
+
+def settle_interpreter() -> None:
+    """For latency-sensitive callers of the Python mirror: run the interpreter's full cyclic garbage collection now and
+    exempt everything alive from later ones (gc.collect() + gc.freeze()).  Importing this package, numpy and torch leaves
+    about 170 000 collector-tracked objects behind; CPython's first generation-2 collection over them takes 35-45 ms and
+    otherwise lands inside some later call (measured: always around the 120th-135th orbx_extract of a process).  The
+    library itself is not involved -- a C or C++ caller never sees that pause."""
+    import gc
+    gc.collect()
+    gc.freeze()

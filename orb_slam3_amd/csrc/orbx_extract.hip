@@ -20,6 +20,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "orbx_common.h"
@@ -1638,6 +1641,10 @@ struct orbx_extractor {
     int* h_counts = nullptr;
     // The host entry points replay their whole command sequence (upload, every kernel, downloads) as one
     // HIP graph: a frame is ~20 dependent commands, and launching them one by one costs more than running them.
+    // Large host batches run as a pipeline of chunks instead (extract_host_pipelined): staging copies on helper
+    // threads, uploads on copyIn, kernels on `stream`, downloads on copyOut, ordered by one event per chunk and stage.
+    hipStream_t copyIn = nullptr, copyOut = nullptr;
+    std::vector<hipEvent_t> pipeEvents;
     hipGraphExec_t hostGraph = nullptr;
     struct { int nf, w, h, lap0, lap1; long epoch; } hostGraphKey = {0, 0, 0, 0, 0, -1};
     long geoEpoch = 0;             // bumped whenever the device buffers or the geometry change
@@ -1969,8 +1976,11 @@ extern "C" void orbx_extractor_destroy(orbx_extractor* ex) {
     hipSetDevice(ex->device);
     if (ex->stream) hipStreamSynchronize(ex->stream);
     if (ex->hostGraph) hipGraphExecDestroy(ex->hostGraph);
+    if (ex->copyIn) { hipStreamSynchronize(ex->copyIn); hipStreamDestroy(ex->copyIn); }
+    if (ex->copyOut) { hipStreamSynchronize(ex->copyOut); hipStreamDestroy(ex->copyOut); }
     if (ex->stream) hipStreamDestroy(ex->stream);
     for (hipEvent_t e : ex->evPool) hipEventDestroy(e);
+    for (hipEvent_t e : ex->pipeEvents) hipEventDestroy(e);
     free_geo_buffers(ex);
     hipFree(ex->d_geo); hipFree(ex->d_candCount); hipFree(ex->d_kpCount); hipFree(ex->d_err);
     hipFree(ex->d_rects); hipFree(ex->d_scratch); hipFree(ex->d_outKps); hipFree(ex->d_outDesc); hipFree(ex->d_counts);
@@ -2011,16 +2021,34 @@ static orbx_status ensure_geometry(orbx_extractor* ex, int w, int h) {
 
 // Enqueues every kernel of one batch.  Level 0 of each pyramid slab must already hold the image; the candidate
 // counters are cleared here unless the caller's copy kernel has done it (countersCleared).
+// frame0: the batch occupies the handle's frame slots frame0 .. frame0 + nf - 1 (every per-frame array of the
+// handle is indexed linearly by the frame, so the kernels simply receive offset base pointers); d_kps / d_desc /
+// d_counts are the rows of the batch's first frame.  dyn == nullptr with ndyn > 0: the rectangles are already on
+// the device (a later chunk of the same host call).
 static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1, const orbx_rect* dyn, int ndyn,
                                  orbx_keypoint* d_kps, uint8_t* d_desc, int capacity, int* d_counts, hipStream_t st,
-                                 bool countersCleared = false) {
+                                 bool countersCleared = false, int frame0 = 0) {
     const OrbxFrameGeo& g = ex->geo;
     const int nl = g.nlevels;
     ORBX_REQUIRE(ndyn >= 0 && ndyn <= kOrbxMaxRects, "at most %d dynamic rectangles", kOrbxMaxRects);
-    if (ndyn > 0) ORBX_HIP_TRY(hipMemcpyAsync(ex->d_rects, dyn, ndyn * sizeof(orbx_rect), hipMemcpyHostToDevice, st));
+    ORBX_REQUIRE(frame0 >= 0 && frame0 + nf <= ex->prm.max_batch, "frames %d .. %d outside the handle's %d slots", frame0,
+                 frame0 + nf - 1, ex->prm.max_batch);
+    if (ndyn > 0 && dyn) ORBX_HIP_TRY(hipMemcpyAsync(ex->d_rects, dyn, ndyn * sizeof(orbx_rect), hipMemcpyHostToDevice, st));
+    // the slots' views of the handle's arrays
+    struct {
+        uint8_t* d_pyr; OrbxCand* d_cands; uint16_t* d_keyNode; OrbxLevelKp* d_levelKps; int *d_candCount, *d_kpCount;
+        OrbxDescWork* d_descWork;
+    } V;
+    V.d_pyr = ex->d_pyr + (size_t)frame0 * g.pyrBytes;
+    V.d_cands = ex->d_cands + (size_t)frame0 * g.candTotal;
+    V.d_keyNode = ex->d_keyNode + (size_t)frame0 * g.candTotal;
+    V.d_levelKps = ex->d_levelKps + (size_t)frame0 * g.kpTotal;
+    V.d_candCount = ex->d_candCount + (size_t)frame0 * nl;
+    V.d_kpCount = ex->d_kpCount + (size_t)frame0 * nl;
+    V.d_descWork = ex->d_descWork + (size_t)frame0 * g.kpTotal;
     // the only per-batch state that must start at zero; the quadtree writes every keypoint count and
     // the error record is cleared when it is read (orbx_extract_status)
-    if (!countersCleared) ORBX_HIP_TRY(hipMemsetAsync(ex->d_candCount, 0, (size_t)nf * nl * sizeof(int), st));
+    if (!countersCleared) ORBX_HIP_TRY(hipMemsetAsync(V.d_candCount, 0, (size_t)nf * nl * sizeof(int), st));
     if (ex->timing && ex->evUsed + kTimedStages + 1 > 4096 * (size_t)(kTimedStages + 1)) resolve_timing(ex);
     mark(ex, st);   // end of copy-in (its start is marked by the caller)
     for (int l = 1; l < nl; ++l) {
@@ -2028,7 +2056,7 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
         const int groups = (g.lv[l].h + kResizeRows - 1) / kResizeRows;
         const int pyrThreads = pyr_threads_for(g.w, g.h);
         dim3 grid((unsigned)(((long long)lanes * groups + pyrThreads - 1) / pyrThreads), nf);
-        hipLaunchKernelGGL(k_resize, grid, dim3(pyrThreads), 0, st, ex->d_geo, l, ex->d_pyr, g.pyrBytes, ex->d_xofs, ex->d_xcoef,
+        hipLaunchKernelGGL(k_resize, grid, dim3(pyrThreads), 0, st, ex->d_geo, l, V.d_pyr, g.pyrBytes, ex->d_xofs, ex->d_xcoef,
                            ex->d_yofs, ex->d_ycoef, lanes, lanes == 1 ? 0xFFFFFFFFu : (uint32_t)(0x100000000ull / (unsigned)lanes));
     }
     mark(ex, st);
@@ -2038,30 +2066,30 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
                                        ? (unsigned int)((1ull << 32) / (unsigned int)g.totalCells) + 1u : 0u;
     if (g.tileP == 48)
         hipLaunchKernelGGL(k_fast<48>, dim3(g.totalCells, nf), dim3(kFastThreads), (size_t)g.fastLds, st, ex->d_geo, ex->d_cells,
-                           ex->d_pyr, g.pyrBytes, ex->d_cands, ex->d_candCount, ex->prm.ini_th_fast, ex->prm.min_th_fast,
+                           V.d_pyr, g.pyrBytes, V.d_cands, V.d_candCount, ex->prm.ini_th_fast, ex->prm.min_th_fast,
                            ex->d_rects, ndyn, ex->d_err, g.tileP, g.tileR, g.fastQueueOff, nl, cellMagic);
     else
         hipLaunchKernelGGL(k_fast<0>, dim3(g.totalCells, nf), dim3(kFastThreads), (size_t)g.fastLds, st, ex->d_geo, ex->d_cells,
-                           ex->d_pyr, g.pyrBytes, ex->d_cands, ex->d_candCount, ex->prm.ini_th_fast, ex->prm.min_th_fast,
+                           V.d_pyr, g.pyrBytes, V.d_cands, V.d_candCount, ex->prm.ini_th_fast, ex->prm.min_th_fast,
                            ex->d_rects, ndyn, ex->d_err, g.tileP, g.tileR, g.fastQueueOff, nl, cellMagic);
     mark(ex, st);
     const size_t qtLds = (size_t)g.maxNodeCap * 56 + kQtThreadsMax * sizeof(int);
     switch (qt_threads_for(ex->prm.nfeatures, nf)) {
         case 128:
-            hipLaunchKernelGGL(k_quadtree<128>, dim3(nl, nf), dim3(128), qtLds, st, ex->d_geo, ex->d_cands, ex->d_candCount,
-                               ex->d_keyNode, ex->d_levelKps, ex->d_kpCount, ex->d_err);
+            hipLaunchKernelGGL(k_quadtree<128>, dim3(nl, nf), dim3(128), qtLds, st, ex->d_geo, V.d_cands, V.d_candCount,
+                               V.d_keyNode, V.d_levelKps, V.d_kpCount, ex->d_err);
             break;
         case 256:
-            hipLaunchKernelGGL(k_quadtree<256>, dim3(nl, nf), dim3(256), qtLds, st, ex->d_geo, ex->d_cands, ex->d_candCount,
-                               ex->d_keyNode, ex->d_levelKps, ex->d_kpCount, ex->d_err);
+            hipLaunchKernelGGL(k_quadtree<256>, dim3(nl, nf), dim3(256), qtLds, st, ex->d_geo, V.d_cands, V.d_candCount,
+                               V.d_keyNode, V.d_levelKps, V.d_kpCount, ex->d_err);
             break;
         default:
-            hipLaunchKernelGGL(k_quadtree<512>, dim3(nl, nf), dim3(512), qtLds, st, ex->d_geo, ex->d_cands, ex->d_candCount,
-                               ex->d_keyNode, ex->d_levelKps, ex->d_kpCount, ex->d_err);
+            hipLaunchKernelGGL(k_quadtree<512>, dim3(nl, nf), dim3(512), qtLds, st, ex->d_geo, V.d_cands, V.d_candCount,
+                               V.d_keyNode, V.d_levelKps, V.d_kpCount, ex->d_err);
     }
     mark(ex, st);
-    hipLaunchKernelGGL(k_layout, dim3(nf), dim3(kLayThreads), 0, st, ex->d_geo, ex->d_levelKps, ex->d_kpCount, lap0, lap1,
-                       capacity, d_counts, ex->d_descWork, ex->d_err);
+    hipLaunchKernelGGL(k_layout, dim3(nf), dim3(kLayThreads), 0, st, ex->d_geo, V.d_levelKps, V.d_kpCount, lap0, lap1,
+                       capacity, d_counts, V.d_descWork, ex->d_err);
     mark(ex, st);
     // A frame keeps at most min(kpTotal, capacity) keypoints: one wave each.  The kernel divides its block index
     // by the grid width with a reciprocal, m = floor(2^32 / d) + 1, exact while blocks * d < 2^32.
@@ -2069,12 +2097,28 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
     const unsigned int frameMagic =
         ((unsigned long long)descGrid * nf) * descGrid < (1ull << 32) && descGrid > 1 ? (unsigned int)((1ull << 32) / descGrid) + 1u : 0u;
     if (descGrid > 0)
-        hipLaunchKernelGGL(k_describe, dim3(descGrid, nf), dim3(64 * kDescWaves), 0, st, ex->d_geo, ex->d_pyr, g.pyrBytes,
-                           ex->d_descWork, g.kpTotal, frameMagic, d_counts, d_kps, d_desc, capacity);
+        hipLaunchKernelGGL(k_describe, dim3(descGrid, nf), dim3(64 * kDescWaves), 0, st, ex->d_geo, V.d_pyr, g.pyrBytes,
+                           V.d_descWork, g.kpTotal, frameMagic, d_counts, d_kps, d_desc, capacity);
     mark(ex, st);
     ORBX_HIP_TRY(hipGetLastError());
-    ex->lastFrames = nf;
+    ex->lastFrames = std::max(frame0 + nf, frame0 ? ex->lastFrames : 0);
     return ORBX_OK;
+}
+
+// Level-0 copy + every kernel for n_frames images into the handle's frame slots frame0 .. (geometry already ensured).
+static orbx_status enqueue_images(orbx_extractor* ex, const uint8_t* d_images, int n_frames, int width, int height,
+                                  ptrdiff_t row_stride, ptrdiff_t frame_stride, int lap0, int lap1, const orbx_rect* dyn_host,
+                                  int ndyn, orbx_keypoint* d_keypoints, uint8_t* d_descriptors, int capacity, int* d_counts,
+                                  hipStream_t st, int frame0) {
+    const int chunksPerRow = (width + 15) / 16;
+    const int pyrThreads = pyr_threads_for(width, height);
+    dim3 grid((unsigned)(((long long)chunksPerRow * height + pyrThreads - 1) / pyrThreads), n_frames);
+    const int aligned16 = ((((uintptr_t)d_images) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
+    mark(ex, st);
+    hipLaunchKernelGGL(k_copy_level0, grid, dim3(pyrThreads), 0, st, ex->d_geo, d_images, (long long)row_stride,
+                       (long long)frame_stride, ex->d_pyr + (size_t)frame0 * ex->geo.pyrBytes, ex->geo.pyrBytes, aligned16,
+                       chunksPerRow, ex->d_candCount + (size_t)frame0 * ex->geo.nlevels);
+    return enqueue_batch(ex, n_frames, lap0, lap1, dyn_host, ndyn, d_keypoints, d_descriptors, capacity, d_counts, st, true, frame0);
 }
 
 extern "C" orbx_status orbx_extract_batch_device(orbx_extractor* ex, const uint8_t* d_images, int n_frames, int width,
@@ -2084,18 +2128,13 @@ extern "C" orbx_status orbx_extract_batch_device(orbx_extractor* ex, const uint8
     ORBX_REQUIRE(ex && d_images && d_keypoints && d_descriptors && d_counts, "null argument");
     ORBX_REQUIRE(n_frames >= 1 && n_frames <= ex->prm.max_batch, "n_frames %d outside [1, %d]", n_frames, ex->prm.max_batch);
     ORBX_REQUIRE(width > 0 && height > 0 && row_stride >= width, "bad image size / stride");
+    ORBX_REQUIRE(ndyn == 0 || dyn_host, "null rectangle list");
     ORBX_HIP_TRY(hipSetDevice(ex->device));
     orbx_status s = ensure_geometry(ex, width, height);
     if (s != ORBX_OK) return s;
-    hipStream_t st = (hipStream_t)stream;   // taken literally: NULL is the device's default stream
-    const int chunksPerRow = (width + 15) / 16;
-    const int pyrThreads = pyr_threads_for(width, height);
-    dim3 grid((unsigned)(((long long)chunksPerRow * height + pyrThreads - 1) / pyrThreads), n_frames);
-    const int aligned16 = ((((uintptr_t)d_images) | (uintptr_t)row_stride | (uintptr_t)frame_stride) & 15) == 0;
-    mark(ex, st);
-    hipLaunchKernelGGL(k_copy_level0, grid, dim3(pyrThreads), 0, st, ex->d_geo, d_images, (long long)row_stride,
-                       (long long)frame_stride, ex->d_pyr, ex->geo.pyrBytes, aligned16, chunksPerRow, ex->d_candCount);
-    return enqueue_batch(ex, n_frames, lap0, lap1, dyn_host, ndyn, d_keypoints, d_descriptors, capacity, d_counts, st, true);
+    // stream taken literally: NULL is the device's default stream
+    return enqueue_images(ex, d_images, n_frames, width, height, row_stride, frame_stride, lap0, lap1, dyn_host, ndyn,
+                          d_keypoints, d_descriptors, capacity, d_counts, (hipStream_t)stream, 0);
 }
 
 extern "C" orbx_status orbx_extract_batch_staged_device(orbx_extractor* ex, orbx_stager* stager, const uint8_t* d_src,
@@ -2177,6 +2216,11 @@ static orbx_status ensure_host_staging(orbx_extractor* ex) {
     return ORBX_OK;
 }
 
+static int host_chunk_frames(size_t frameBytes, int n_frames);
+static orbx_status extract_host_pipelined(orbx_extractor* ex, const uint8_t* const* images, int n_frames, int width,
+                                          int height, ptrdiff_t stride, int lap0, int lap1, orbx_keypoint* keypoints,
+                                          uint8_t* descriptors, int capacity, int* n_out, int* mono_index_out);
+
 static orbx_status extract_host(orbx_extractor* ex, const uint8_t* const* images, int n_frames, int width, int height,
                                 ptrdiff_t stride, int lap0, int lap1, const orbx_rect* dyn, int ndyn,
                                 orbx_keypoint* keypoints, uint8_t* descriptors, int capacity, int* n_out,
@@ -2201,6 +2245,13 @@ static orbx_status extract_host(orbx_extractor* ex, const uint8_t* const* images
     s = ensure_host_staging(ex);
     if (s != ORBX_OK) return s;
     const size_t frameBytes = (size_t)width * height;
+    // 40 MB of images or more (measured on MI355X / PCIe 5: 111 frames of 752 x 480, 20 of 1920 x 1080; below that the
+    // single captured sequence is as fast): overlap staging, upload, kernels and download.  Rectangles and per-kernel
+    // timing keep the single-sequence path below.
+    if (ndyn == 0 && !ex->timing && n_frames >= 12 && (size_t)n_frames * frameBytes >= ((size_t)40 << 20) &&
+        !getenv("ORBX_HOST_NO_PIPELINE"))
+        return extract_host_pipelined(ex, images, n_frames, width, height, stride, lap0, lap1, keypoints, descriptors, capacity,
+                                      n_out, mono_index_out);
     for (int f = 0; f < n_frames; ++f) {
         if (!images[f]) { orbx_set_error("empty image"); return ORBX_ERR_EMPTY; }
         uint8_t* dst = ex->h_in + (size_t)f * frameBytes;
@@ -2264,6 +2315,151 @@ static orbx_status extract_host(orbx_extractor* ex, const uint8_t* const* images
         }
     }
     return ORBX_OK;
+}
+
+// A large host batch as a pipeline of chunks.  Helper threads pack the images of whole chunks into the pinned
+// buffer, running ahead of the calling thread, which uploads a packed chunk on `copyIn`, enqueues its kernels on
+// `stream` into the chunk's own frame slots and its downloads on `copyOut`; as soon as a chunk's downloads are back,
+// whichever thread is free hands its rows out to the caller's arrays.  Every chunk owns its range of every staging
+// array (they are sized for max_batch frames), so nothing is reused inside a call, and a frame's kernels see only
+// that frame's slot: the results are those of the one-image path.
+static int host_chunk_frames(size_t frameBytes, int n_frames) {
+    size_t want = (size_t)16 << 20;                            // bytes per upload
+    if (const char* v = getenv("ORBX_HOST_CHUNK_MB")) want = (size_t)std::max(1, atoi(v)) << 20;
+    const int byBytes = (int)std::min<size_t>(32, std::max<size_t>(4, want / std::max<size_t>(frameBytes, 1)));
+    return std::max(4, std::min(byBytes, (n_frames + 3) / 4));   // at least four chunks when the batch allows it
+}
+
+static orbx_status extract_host_pipelined(orbx_extractor* ex, const uint8_t* const* images, int n_frames, int width,
+                                          int height, ptrdiff_t stride, int lap0, int lap1, orbx_keypoint* keypoints,
+                                          uint8_t* descriptors, int capacity, int* n_out, int* mono_index_out) {
+    const size_t frameBytes = (size_t)width * height;
+    const int C = host_chunk_frames(frameBytes, n_frames);
+    const int nChunks = (n_frames + C - 1) / C;
+    if (!ex->copyIn) ORBX_HIP_TRY(hipStreamCreateWithFlags(&ex->copyIn, hipStreamNonBlocking));
+    if (!ex->copyOut) ORBX_HIP_TRY(hipStreamCreateWithFlags(&ex->copyOut, hipStreamNonBlocking));
+    while (ex->pipeEvents.size() < (size_t)3 * nChunks) {
+        hipEvent_t e;
+        ORBX_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ex->pipeEvents.push_back(e);
+    }
+    for (int f = 0; f < n_frames; ++f)
+        if (!images[f]) { orbx_set_error("empty image"); return ORBX_ERR_EMPTY; }
+    int helpers = 3;
+    if (const char* v = getenv("ORBX_HOST_THREADS")) helpers = std::max(1, std::min(15, atoi(v) - 1));
+    const unsigned hw = std::thread::hardware_concurrency();
+    if (hw > 1 && (unsigned)helpers > hw - 1) helpers = (int)hw - 1;
+    helpers = std::min(helpers, nChunks);
+
+    orbx_status s = ORBX_OK;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        // chunk states, written by one thread and polled by others
+        std::vector<std::atomic<int>> staged(nChunks), enqueued(nChunks);
+        for (int k = 0; k < nChunks; ++k) { staged[k].store(0); enqueued[k].store(0); }
+        std::atomic<int> nextOut{0}, abortAll{0}, outError{ORBX_OK};
+        std::atomic<int> badFrame{-1};
+        auto stage_chunk = [&](int k) {
+            const int f0 = k * C, c = std::min(C, n_frames - f0);
+            for (int f = f0; f < f0 + c; ++f) {
+                uint8_t* dst = ex->h_in + (size_t)f * frameBytes;
+                if (stride == width) memcpy(dst, images[f], frameBytes);
+                else for (int y = 0; y < height; ++y) memcpy(dst + (size_t)y * width, images[f] + (ptrdiff_t)y * stride, width);
+            }
+            staged[k].store(1, std::memory_order_release);
+        };
+        // Hands out the chunks whose downloads are complete, one after the other, until none is left (or, with
+        // `onlyReady`, until the next one is not back yet).
+        auto hand_out = [&](bool onlyReady) {
+            for (;;) {
+                const int k = nextOut.load();
+                if (k >= nChunks || abortAll.load()) return;
+                if (!enqueued[k].load(std::memory_order_acquire)) {
+                    if (onlyReady) return;
+                    std::this_thread::sleep_for(std::chrono::microseconds(20));     // no spinning beside the enqueuing thread
+                    continue;
+                }
+                hipEvent_t evOut = ex->pipeEvents[3 * k + 2];
+                if (onlyReady && hipEventQuery(evOut) != hipSuccess) return;
+                int claim = k;
+                if (!nextOut.compare_exchange_strong(claim, k + 1)) continue;     // another thread took it
+                if (hipEventSynchronize(evOut) != hipSuccess) { outError.store(ORBX_ERR_HIP); return; }
+                const int f0 = k * C, c = std::min(C, n_frames - f0);
+                for (int f = f0; f < f0 + c; ++f) {
+                    const int n = ex->h_counts[2 * f];
+                    n_out[f] = n;
+                    mono_index_out[f] = ex->h_counts[2 * f + 1];
+                    if (n > capacity) { int none = -1; badFrame.compare_exchange_strong(none, f); outError.store(ORBX_ERR_CAPACITY); continue; }
+                    if (n <= 0) continue;
+                    if (!(keypoints && descriptors)) { outError.store(ORBX_ERR_INVALID); continue; }
+                    memcpy(keypoints + (size_t)f * capacity, ex->h_outKps + (size_t)f * ex->outCap, n * sizeof(orbx_keypoint));
+                    memcpy(descriptors + (size_t)f * capacity * 32, ex->h_outDesc + (size_t)f * ex->outCap * 32, (size_t)n * 32);
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < helpers; ++t)
+            pool.emplace_back([&, t] {
+                hipSetDevice(ex->device);
+                for (int k = t; k < nChunks && !abortAll.load(); k += helpers) stage_chunk(k);
+                hand_out(false);
+            });
+        hipError_t he = hipSuccess;
+        auto hip_ok = [&](hipError_t e) { if (e != hipSuccess && he == hipSuccess) he = e; return e == hipSuccess; };
+        const bool trace = getenv("ORBX_HOST_TRACE") != nullptr;
+        auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tStart = now();
+        double tWait = 0, tEnq = 0;
+        for (int k = 0; k < nChunks && s == ORBX_OK && he == hipSuccess; ++k) {
+            const int f0 = k * C, c = std::min(C, n_frames - f0);
+            const double w0 = now();
+            while (!staged[k].load(std::memory_order_acquire)) std::this_thread::yield();
+            const double w1 = now();
+            tWait += w1 - w0;
+            struct EnqTimer { double& acc; double t0; decltype(now)& clk; ~EnqTimer() { acc += clk() - t0; } } enqTimer{tEnq, w1, now};
+            hipEvent_t evIn = ex->pipeEvents[3 * k], evK = ex->pipeEvents[3 * k + 1], evOut = ex->pipeEvents[3 * k + 2];
+            if (!hip_ok(hipMemcpyAsync(ex->d_in + (size_t)f0 * frameBytes, ex->h_in + (size_t)f0 * frameBytes, (size_t)c * frameBytes,
+                                       hipMemcpyHostToDevice, ex->copyIn)) ||
+                !hip_ok(hipEventRecord(evIn, ex->copyIn)) || !hip_ok(hipStreamWaitEvent(ex->stream, evIn, 0)))
+                break;
+            s = enqueue_images(ex, ex->d_in + (size_t)f0 * frameBytes, c, width, height, width, (ptrdiff_t)frameBytes, lap0, lap1,
+                               nullptr, 0, ex->d_outKps + (size_t)f0 * ex->outCap, ex->d_outDesc + (size_t)f0 * ex->outCap * 32,
+                               ex->outCap, ex->d_counts + 2 * f0, ex->stream, f0);
+            if (s != ORBX_OK) break;
+            if (!hip_ok(hipEventRecord(evK, ex->stream)) || !hip_ok(hipStreamWaitEvent(ex->copyOut, evK, 0)) ||
+                !hip_ok(hipMemcpyAsync(ex->h_counts + 2 * f0, ex->d_counts + 2 * f0, (size_t)c * 2 * sizeof(int), hipMemcpyDeviceToHost, ex->copyOut)) ||
+                !hip_ok(hipMemcpyAsync(ex->h_outKps + (size_t)f0 * ex->outCap, ex->d_outKps + (size_t)f0 * ex->outCap,
+                                       (size_t)c * ex->outCap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, ex->copyOut)) ||
+                !hip_ok(hipMemcpyAsync(ex->h_outDesc + (size_t)f0 * ex->outCap * 32, ex->d_outDesc + (size_t)f0 * ex->outCap * 32,
+                                       (size_t)c * ex->outCap * 32, hipMemcpyDeviceToHost, ex->copyOut)) ||
+                (k == nChunks - 1 && !hip_ok(hipMemcpyAsync(ex->h_err, ex->d_err, sizeof(OrbxErr), hipMemcpyDeviceToHost, ex->copyOut))) ||
+                !hip_ok(hipEventRecord(evOut, ex->copyOut)))
+                break;
+            enqueued[k].store(1, std::memory_order_release);
+        }
+        const double tLoop = now();
+        if (s != ORBX_OK || he != hipSuccess) abortAll.store(1);
+        else hand_out(false);
+        const double tOut = now();
+        for (std::thread& t : pool) t.join();
+        if (trace)
+            fprintf(stderr, "orbx host pipeline: %d frames, %d chunks of %d, %d helpers: waited for staging %.0f us, enqueued %.0f us, "
+                            "hand-out tail %.0f us, join %.0f us, total %.0f us\n", n_frames, nChunks, C, helpers, tWait, tEnq,
+                    tOut - tLoop, now() - tOut, now() - tStart);
+        // nothing may be left in flight on the handle's streams, whatever happened
+        const hipError_t e1 = hipStreamSynchronize(ex->copyIn), e2 = hipStreamSynchronize(ex->stream), e3 = hipStreamSynchronize(ex->copyOut);
+        if (s != ORBX_OK) return s;
+        ORBX_HIP_TRY(he); ORBX_HIP_TRY(e1); ORBX_HIP_TRY(e2); ORBX_HIP_TRY(e3);
+        // a candidate-buffer overflow shows only now: the buffers have been regrown, the whole batch runs again and the
+        // rows handed out so far are overwritten
+        s = extract_status_from(ex, *ex->h_err);
+        if (s == ORBX_ERR_CAPACITY && ex->h_err->cand_overflow) { s = ensure_host_staging(ex); if (s != ORBX_OK) return s; continue; }
+        if (s != ORBX_OK) return s;
+        if (outError.load() == ORBX_ERR_CAPACITY) orbx_set_error("frame %d has %d keypoints, capacity is %d", badFrame.load(), n_out[badFrame.load()], capacity);
+        else if (outError.load() == ORBX_ERR_INVALID) orbx_set_error("null output buffer");
+        else if (outError.load() == ORBX_ERR_HIP) orbx_set_error("hipEventSynchronize failed");
+        return (orbx_status)outError.load();
+    }
+    return s;
 }
 
 extern "C" orbx_status orbx_extract_batch(orbx_extractor* ex, const uint8_t* const* images, int n_frames, int width,

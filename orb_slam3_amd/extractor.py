@@ -101,28 +101,38 @@ class ORBextractor:
         self.max_keypoints = now
         return True
 
-    def extract_batch(self, images, vLappingArea=(0, 0)):
-        """One pass of every kernel over a list of equally sized host images.
-        Returns a list of (keypoints, descriptors, monoIndex)."""
+    def extract_batch(self, images, vLappingArea=(0, 0), copy=True):
+        """One pass of every kernel over a list of equally sized host images (orbx_extract_batch: a batch of three
+        upload chunks or more is pipelined -- staging, upload, kernels and download overlap).
+        Returns a list of (keypoints, descriptors, monoIndex); copy=False returns views into two arrays shared
+        by the whole batch instead of per-frame copies."""
         nf = len(images)
         assert 1 <= nf <= self.max_batch
-        imgs = [np.ascontiguousarray(im) for im in images]
-        h, w = imgs[0].shape
+        h, w = images[0].shape
+        # images that share one row stride (views into wider buffers, as cv::Mat ROIs are) go in as they are
+        stride = images[0].strides[0]
+        if all(im.strides == (stride, 1) for im in images) and stride >= w:
+            imgs = list(images)
+        else:
+            imgs = [im if im.flags.c_contiguous else np.ascontiguousarray(im) for im in images]
+            stride = w
         assert all(im.shape == (h, w) and im.dtype == np.uint8 for im in imgs)
-        ptrs = (C.c_void_p * nf)(*[im.ctypes.data for im in imgs])
+        ptrs = (C.c_void_p * nf)(*[im.__array_interface__["data"][0] for im in imgs])
         n = np.zeros(nf, np.int32)
         mono = np.zeros(nf, np.int32)
         while True:
             cap = self.max_keypoints
-            kps = np.zeros((nf, cap), KP_DTYPE)
-            desc = np.zeros((nf, cap, 32), np.uint8)
+            kps = np.empty((nf, cap), KP_DTYPE)
+            desc = np.empty((nf, cap, 32), np.uint8)
             try:
-                check(self._L.orbx_extract_batch(self._h, ptrs, nf, w, h, w, int(vLappingArea[0]), int(vLappingArea[1]),
+                check(self._L.orbx_extract_batch(self._h, ptrs, nf, w, h, stride, int(vLappingArea[0]), int(vLappingArea[1]),
                                                  ptr(kps), ptr(desc), cap, ptr(n), ptr(mono)))
                 break
             except OrbxError:
                 if not self._capacity_grew():
                     raise
+        if not copy:
+            return [(kps[f, :n[f]], desc[f, :n[f]], int(mono[f])) for f in range(nf)]
         return [(kps[f, :n[f]].copy(), desc[f, :n[f]].copy(), int(mono[f])) for f in range(nf)]
 
     def extract_batch_device(self, d_images, vLappingArea=(0, 0), out=None, stream=None):

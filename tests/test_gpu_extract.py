@@ -342,6 +342,35 @@ def test_batch_equals_single_and_is_deterministic(oracle):
         assert np.array_equal(outs[0][0][f, :n], outs[1][0][f, :n]) and np.array_equal(outs[0][1][f, :n], outs[1][1][f, :n])
 
 
+def test_pipelined_host_batch_equals_single_frames(oracle):
+    """orbx_extract_batch with three chunks or more runs as a pipeline (staging copies on helper threads, uploads,
+    kernels in per-chunk frame slots and downloads on three streams): every frame must come out as from the
+    one-image entry point, for a row-strided input, a ragged last chunk and two calls in a row."""
+    A = _gpu()
+    n = 120                                                    # 752x480: 43 MB -> four chunks of 30 frames
+    scenes = [synth.scene(752, 480, 300 + i) for i in range(10)]
+    imgs = [scenes[i % 10] if i % 3 else np.ascontiguousarray(scenes[i % 10][:, ::-1]) for i in range(n)]
+    g = A.ORBextractor(1000, 1.2, 8, 20, 7, max_width=752, max_height=480, max_batch=n)
+    g1 = A.ORBextractor(1000, 1.2, 8, 20, 7, max_width=752, max_height=480)
+    single = {}
+    for i in range(n):
+        key = (i % 10, bool(i % 3))
+        if key not in single:
+            single[key] = g1(imgs[i], (0, 1000))
+    for _ in range(2):
+        batch = g.extract_batch(imgs, (0, 1000))
+        assert len(batch) == n
+        for i, b in enumerate(batch):
+            _same(*single[(i % 10, bool(i % 3))], *b)
+    _same(*oracle.Extractor(1000)(imgs[119], (0, 1000)), *batch[119])
+    # a ragged last chunk (115 = 3 x 29 + 28 frames) of images that are views with a row stride
+    wide = [np.pad(s, ((0, 0), (0, 16))) for s in scenes]
+    many = [wide[i % 10][:, :752] for i in range(115)]
+    out = g.extract_batch(many, (0, 0))
+    for i in (0, 28, 29, 57, 58, 86, 87, 114):
+        _same(*g1(scenes[i % 10], (0, 0)), *out[i])
+
+
 def test_full_hd_5000_features(oracle):
     # the batched 1920x1080 / 5000-feature frame shape, one frame against the oracle
     A = _gpu()

@@ -10,9 +10,10 @@ from orb_slam3_amd import synth
 W, H = 752, 480
 imgs = [synth.scene(W, H, 40 + i) for i in range(8)]
 ex1 = A.ORBextractor(1000, 1.2, 8, 20, 7, W, H)
-# One extraction per process (about the 133rd) takes 35-44 ms, whatever the handle: make it happen before anything
-# is timed.
-for i in range(200):
+# CPython's first full garbage collection (35-45 ms over the ~170 000 objects the imports leave behind) would
+# otherwise land inside one of the first ~130 calls: run it now (profiles/r03_slow_call_gc_probe.txt).
+A.settle_interpreter()
+for i in range(20):
     ex1(imgs[i % 8], (0, 0))
 t0 = time.perf_counter()
 n = 50
