@@ -104,8 +104,8 @@ class ORBextractor:
     def extract_batch(self, images, vLappingArea=(0, 0), copy=True):
         """One pass of every kernel over a list of equally sized host images (orbx_extract_batch: a batch of three
         upload chunks or more is pipelined -- staging, upload, kernels and download overlap).
-        Returns a list of (keypoints, descriptors, monoIndex); copy=False returns views into two arrays shared
-        by the whole batch instead of per-frame copies."""
+        Returns a list of (keypoints, descriptors, monoIndex); copy=False returns views into two arrays that the
+        extractor keeps and overwrites in its next batch call, instead of per-frame copies."""
         nf = len(images)
         assert 1 <= nf <= self.max_batch
         h, w = images[0].shape
@@ -122,8 +122,16 @@ class ORBextractor:
         mono = np.zeros(nf, np.int32)
         while True:
             cap = self.max_keypoints
-            kps = np.empty((nf, cap), KP_DTYPE)
-            desc = np.empty((nf, cap, 32), np.uint8)
+            # copy=False: the two result arrays belong to the extractor and are reused by the next call of the same
+            # shape, as a C++ caller reuses its vectors (fresh arrays cost a page fault per 4 KB the library writes)
+            held = getattr(self, "_batch_out", None)
+            if not copy and held is not None and held[0].shape == (nf, cap):
+                kps, desc = held
+            else:
+                kps = np.empty((nf, cap), KP_DTYPE)
+                desc = np.empty((nf, cap, 32), np.uint8)
+                if not copy:
+                    self._batch_out = (kps, desc)
             try:
                 check(self._L.orbx_extract_batch(self._h, ptrs, nf, w, h, stride, int(vLappingArea[0]), int(vLappingArea[1]),
                                                  ptr(kps), ptr(desc), cap, ptr(n), ptr(mono)))
@@ -134,6 +142,34 @@ class ORBextractor:
         if not copy:
             return [(kps[f, :n[f]], desc[f, :n[f]], int(mono[f])) for f in range(nf)]
         return [(kps[f, :n[f]].copy(), desc[f, :n[f]].copy(), int(mono[f])) for f in range(nf)]
+
+    def extract_batch_arrays(self, stack, vLappingArea=(0, 0)):
+        """orbx_extract_batch on a stack of host images [n, H, W] (uint8, unit pixel stride; any row and frame
+        stride), results as whole arrays: (keypoints [n, cap] KP_DTYPE, descriptors [n, cap, 32], n_keypoints [n],
+        monoIndex [n]); frame f's rows are [f, :n_keypoints[f]].  The arrays belong to the extractor and are
+        overwritten by its next call of the same shape.  No per-frame Python objects are made: this is the mirror's
+        counterpart of a C++ caller that passes plain buffers."""
+        assert stack.ndim == 3 and stack.dtype == np.uint8 and stack.strides[2] == 1
+        nf, h, w = stack.shape
+        assert 1 <= nf <= self.max_batch and stack.strides[1] >= w
+        base = stack.__array_interface__["data"][0]
+        ptrs = (base + np.arange(nf, dtype=np.uint64) * np.uint64(stack.strides[0])).astype(np.uint64)
+        held = getattr(self, "_arrays_out", None)
+        while True:
+            cap = self.max_keypoints
+            if held is None or held[0].shape != (nf, cap):
+                held = (np.empty((nf, cap), KP_DTYPE), np.empty((nf, cap, 32), np.uint8), np.zeros(nf, np.int32),
+                        np.zeros(nf, np.int32))
+                self._arrays_out = held
+            kps, desc, n, mono = held
+            try:
+                check(self._L.orbx_extract_batch(self._h, ptr(ptrs), nf, w, h, stack.strides[1], int(vLappingArea[0]),
+                                                 int(vLappingArea[1]), ptr(kps), ptr(desc), cap, ptr(n), ptr(mono)))
+                return kps, desc, n, mono
+            except OrbxError:
+                if not self._capacity_grew():
+                    raise
+                held = None
 
     def extract_batch_device(self, d_images, vLappingArea=(0, 0), out=None, stream=None):
         """d_images: torch uint8 CUDA tensor [n, H, W] (row stride W, or any row/frame stride).
