@@ -230,19 +230,22 @@ orbx_status orbx_descriptor_distance(const uint8_t* a, const uint8_t* b, int n, 
 orbx_status orbx_hamming_knn2(const uint8_t* query, int n_query, const uint8_t* train, int64_t n_train,
                               orbx_match2* out);
 /* Device-resident variant; train indices are reported as base_index + row, so a shard of a
- * larger map reports global indices.  `workspace` must hold orbx_knn2_workspace_bytes(). */
+ * larger map reports global indices.  `workspace` (16-byte aligned) must hold orbx_knn2_workspace_bytes(), which
+ * depends on the compute-unit count of the device that is CURRENT when it is asked: ask with the search's device
+ * current (a smaller figure from another device makes the search return ORBX_ERR_INVALID, never overrun). */
 size_t orbx_knn2_workspace_bytes(int n_query, int64_t n_train);
 orbx_status orbx_hamming_knn2_device(const uint8_t* d_query, int n_query, const uint8_t* d_train, int64_t n_train,
                                      int64_t base_index, orbx_match2* d_out, void* d_workspace, size_t workspace_bytes,
                                      void* stream);
 /* orbx_hamming_knn2_device for callers that cannot allocate device memory (code under HIP graph
  * capture, serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The
- * per-chunk partial results live in a fixed 16 MiB array inside the library's device image (one copy
+ * partial results and span counters live in a fixed 16 MiB array inside the library's device image (one copy
  * per GPU, held until the process ends) instead of a caller workspace, so the call performs no
- * hipMalloc / hipFree.  n_query is limited to orbx_knn2_static_max_queries() (1 048 576); larger
+ * hipMalloc / hipFree.  n_query is limited to orbx_knn2_static_max_queries() (1 047 552); larger
  * inputs return ORBX_ERR_INVALID.  Results are identical to orbx_hamming_knn2_device.  All calls on
  * one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two threads)
- * race; order them. */
+ * race; order them.  The array's address is looked up on the first call per device (or by
+ * orbx_knn2_static_max_queries(), which a caller about to capture a graph calls beforehand). */
 size_t orbx_knn2_static_max_queries(void);
 orbx_status orbx_hamming_knn2_device_static(const uint8_t* d_query, int n_query, const uint8_t* d_train,
                                             int64_t n_train, int64_t base_index, orbx_match2* d_out, void* stream);

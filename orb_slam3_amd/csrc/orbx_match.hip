@@ -10,6 +10,7 @@
 // (v_xor_b32 + v_bcnt_u32_b32), no matrix cores.
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstring>
@@ -215,14 +216,19 @@ extern "C" orbx_status orbx_descriptor_distance(const uint8_t* a, const uint8_t*
 // running best / second best.  Train descriptors are wave-uniform: they are fetched with
 // scalar loads and applied to all 64 x kQpl queries of the wave, so the inner loop is
 // 8 x (v_xor_b32 with an SGPR operand + v_bcnt_u32_b32 accumulate) per pair and one compare.
-// The train set is cut into contiguous chunks (grid.y); every (query group, chunk) writes a
-// partial top-2 with global indices and k_knn2_merge folds the chunks in index order.
-// Ties: strict '<' while scanning ascending indices keeps the lowest index, and the merge
+// The train set is cut into spans of kKnnSpanRows rows.  grid.y = the workers of a query group, as many as
+// fill the chip once; a worker (one wave) takes the next unclaimed span of its query group from a counter until
+// none is left, so waves that the SIMD's arbitration favours simply take more spans and all of them finish
+// within one span of each other (with one fixed slice per wave the slowest wave of a SIMD ran its last third
+// alone, at a third of the issue rate).  Every worker writes one partial top-2 with global indices and
+// k_knn2_merge folds the workers' results.
+// Ties: a worker scans its spans in ascending order with strict '<', which keeps the lowest index, and the merge
 // is lexicographic on (distance, index), which is what a single sequential scan gives.
 // ======================================================================================
 constexpr int kQpl = 4;        // queries per lane
 constexpr int kKnnWaves = 4;
 constexpr int kRowsPerIter = 8;   // train rows fetched (scalar) and applied per loop trip
+constexpr int kKnnSpanRows = 2048;   // rows a worker claims at a time (a multiple of kRowsPerIter)
 
 // Per-query register state.  Four named instances (not an array) so that everything stays in
 // VGPRs: a runtime-indexed array of these would be placed in scratch memory.
@@ -291,6 +297,38 @@ __device__ __forceinline__ void knn_rows4(KnnQuery& s, const uint32_t (&t)[4][8]
     }
 }
 
+// The distances of four rows, without the bookkeeping (knn_rows8 decides once for eight rows).
+__device__ __forceinline__ void knn_dist4(const KnnQuery& s, const uint32_t (&t)[4][8], int (&d)[4]) {
+    uint32_t acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const uint32_t x = s.q[0] ^ t[r][0];
+        asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(acc[r]) : "v"(x));
+    }
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t x = s.q[k] ^ t[r][k];
+            asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[r]) : "v"(x));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = (int)acc[r];
+}
+
+// Second half of an eight-row step: rows gj + 4 .. gj + 7 are in t, the distances of rows gj .. gj + 3 in lo.  One
+// test of the smallest of the eight against the current second best; the replay is in ascending index order.
+__device__ __forceinline__ void knn_rows8_finish(KnnQuery& s, const int (&lo)[4], const uint32_t (&t)[4][8], int gj) {
+    int hi[4];
+    knn_dist4(s, t, hi);
+    const int m = min(min(min(lo[0], lo[1]), min(lo[2], lo[3])), min(min(hi[0], hi[1]), min(hi[2], hi[3])));
+    if (m < s.second) {
+        knn_update(s, lo[0], gj); knn_update(s, lo[1], gj + 1); knn_update(s, lo[2], gj + 2); knn_update(s, lo[3], gj + 3);
+        knn_update(s, hi[0], gj + 4); knn_update(s, hi[1], gj + 5); knn_update(s, hi[2], gj + 6); knn_update(s, hi[3], gj + 7);
+    }
+}
+
 __device__ __forceinline__ void knn_store(const KnnQuery& s, int nq, orbx_match2* __restrict__ part) {
     if (s.qi < nq) {
         orbx_match2 m;
@@ -301,14 +339,13 @@ __device__ __forceinline__ void knn_store(const KnnQuery& s, int nq, orbx_match2
 
 __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restrict__ query, int nq,
                                                           const uint32_t* __restrict__ train, long long nt,
-                                                          long long chunkLen, long long baseIndex,
-                                                          orbx_match2* __restrict__ part) {
+                                                          int nSpans, long long baseIndex,
+                                                          orbx_match2* __restrict__ part, int* __restrict__ spanCounter) {
     static_assert(kQpl == 4 && kRowsPerIter == 8, "the body below is written out for 4 queries x 2 groups of 4 rows");
+    static_assert(kKnnSpanRows % kRowsPerIter == 0, "a span is a whole number of loop trips");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int group = blockIdx.x * kKnnWaves + wave;
-    const long long j0 = (long long)blockIdx.y * chunkLen;
-    const long long j1 = min(nt, j0 + chunkLen);
     if (group * 64 * kQpl >= nq) return;
 
     KnnQuery a, b, c, d;
@@ -318,6 +355,15 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restr
     knn_load(c, query, q0 + 128, nq);
     knn_load(d, query, q0 + 192, nq);
 
+  // the next unclaimed span of this query group; the counter only grows, so the loop ends for every wave once it
+  // has passed nSpans (the host clears the counters before the launch)
+  for (;;) {
+    int span = 0;
+    if (lane == 0) span = atomicAdd(&spanCounter[group], 1);
+    span = __builtin_amdgcn_readfirstlane(span);
+    if (span >= nSpans) break;
+    const long long j0 = (long long)span * kKnnSpanRows;
+    const long long j1 = min(nt, j0 + kKnnSpanRows);
     long long j = j0;
     // 8 rows per trip, fetched as two groups of 4: the scalar loads of the second group are in flight
     // while the first group is applied, and the next trip's first group while the second is applied
@@ -337,7 +383,12 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restr
 #pragma unroll
                 for (int k = 0; k < 8; ++k) tb[r][k] = t[32 + 8 * r + k];
             const int gj = (int)(baseIndex + j);
+#ifdef ORBX_KNN_CHECK8
+            int la[4], lb[4], lc[4], ld[4];
+            knn_dist4(a, ta, la); knn_dist4(b, ta, lb); knn_dist4(c, ta, lc); knn_dist4(d, ta, ld);
+#else
             knn_rows4(a, ta, gj); knn_rows4(b, ta, gj); knn_rows4(c, ta, gj); knn_rows4(d, ta, gj);
+#endif
             // first group of the next trip.  Scalar loads return out of order, so every wait is for all of them:
             // wait for the second group here, before the next loads are issued, not at its first use
             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
@@ -347,7 +398,11 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restr
 #pragma unroll
                     for (int k = 0; k < 8; ++k) ta[r][k] = t[64 + 8 * r + k];
             }
+#ifdef ORBX_KNN_CHECK8
+            knn_rows8_finish(a, la, tb, gj); knn_rows8_finish(b, lb, tb, gj); knn_rows8_finish(c, lc, tb, gj); knn_rows8_finish(d, ld, tb, gj);
+#else
             knn_rows4(a, tb, gj + 4); knn_rows4(b, tb, gj + 4); knn_rows4(c, tb, gj + 4); knn_rows4(d, tb, gj + 4);
+#endif
         }
     }
     for (; j < j1; ++j) {
@@ -361,6 +416,7 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restr
         knn_update(c, knn_dist(c, t0), gj);
         knn_update(d, knn_dist(d, t0), gj);
     }
+  }
     orbx_match2* out = part + (long long)blockIdx.y * nq;
     knn_store(a, nq, out); knn_store(b, nq, out); knn_store(c, nq, out); knn_store(d, nq, out);
 }
@@ -402,31 +458,48 @@ __global__ __launch_bounds__(256) void k_knn2_merge(const orbx_match2* __restric
 
 // Workgroups the current device keeps resident at 8 waves per SIMD (k_knn2 needs < 64 VGPRs): compute units x 8.
 static int knn2_resident_blocks() {
-    static int cached[kMaxDevices] = {};
+    static std::atomic<int> cached[kMaxDevices];          // zero-initialised; several threads may fill an entry, all with the same value
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 2048;
-    if (!cached[dev]) {
+    int v = cached[dev].load(std::memory_order_relaxed);
+    if (!v) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        cached[dev] = cus * 32 / kKnnWaves;
+        v = cus * 32 / kKnnWaves;
+        cached[dev].store(v, std::memory_order_relaxed);
     }
-    return cached[dev];
+    return v;
 }
 
+// Workers (grid.y) per query group: one resident round of the chip and no more -- a grid a few workgroups larger
+// than what fits at once leaves those to start after everything else has finished -- and no more workers than spans.
 static int knn2_chunks(int nq, long long nt) {
     const int groups = (nq + 64 * kQpl - 1) / (64 * kQpl);
     const int blocksPerChunk = (groups + kKnnWaves - 1) / kKnnWaves;
-    // One resident round: as many chunks as fill the chip once and no more.  A grid a few workgroups larger than
-    // what fits at once leaves those to run alone after everything else has finished (2050 workgroups on 2048
-    // slots cost a quarter of the search time); at least 256 train rows per chunk.
     long long want = std::max(1, knn2_resident_blocks() / std::max(blocksPerChunk, 1));
-    long long maxByLen = std::max<long long>(1, nt / 256);
-    long long c = std::max<long long>(1, std::min(want, maxByLen));
+    long long spans = std::max<long long>(1, (nt + kKnnSpanRows - 1) / kKnnSpanRows);
+    long long c = std::max<long long>(1, std::min(want, spans));
     return (int)std::min<long long>(c, 4096);
 }
+static int knn2_groups(int nq) { return (nq + 64 * kQpl - 1) / (64 * kQpl); }
+// the span counters (one int per query group) sit behind the workers' partial results
+static size_t knn2_counter_bytes(int nq) { return ((size_t)knn2_groups(nq) * sizeof(int) + 255) & ~(size_t)255; }
 
+// Sized for the device that is current when the search runs if it is current now; for any device of up to 512 CUs
+// otherwise (the worker count follows the CU count of the current device).
 extern "C" size_t orbx_knn2_workspace_bytes(int n_query, int64_t n_train) {
     if (n_query <= 0 || n_train <= 0) return 16;
-    return (size_t)knn2_chunks(n_query, n_train) * (size_t)n_query * sizeof(orbx_match2);
+    return (size_t)knn2_chunks(n_query, n_train) * (size_t)n_query * sizeof(orbx_match2) + knn2_counter_bytes(n_query);
+}
+
+// Clears the span counters and launches the search into `parts` (workers x n_query rows) with `counters` behind it.
+static void knn2_launch(const uint8_t* d_query, int n_query, const uint8_t* d_train, int64_t n_train, int64_t base_index,
+                        int workers, orbx_match2* parts, int* counters, hipStream_t st) {
+    const int groups = knn2_groups(n_query);
+    const int nSpans = (int)((n_train + kKnnSpanRows - 1) / kKnnSpanRows);
+    (void)hipMemsetAsync(counters, 0, (size_t)groups * sizeof(int), st);
+    dim3 grid((groups + kKnnWaves - 1) / kKnnWaves, workers);
+    hipLaunchKernelGGL(k_knn2, grid, dim3(64 * kKnnWaves), 0, st, (const uint32_t*)d_query, n_query, (const uint32_t*)d_train,
+                       (long long)n_train, nSpans, (long long)base_index, parts, counters);
 }
 
 extern "C" orbx_status orbx_hamming_knn2_device(const uint8_t* d_query, int n_query, const uint8_t* d_train,
@@ -440,13 +513,13 @@ extern "C" orbx_status orbx_hamming_knn2_device(const uint8_t* d_query, int n_qu
     hipStream_t st = (hipStream_t)stream;
     const int chunks = n_train > 0 ? knn2_chunks(n_query, n_train) : 0;
     if (chunks > 0) {
-        ORBX_REQUIRE(d_workspace && workspace_bytes >= (size_t)chunks * n_query * sizeof(orbx_match2), "workspace too small");
-        const long long chunkLen = (n_train + chunks - 1) / chunks;
-        const int groups = (n_query + 64 * kQpl - 1) / (64 * kQpl);
-        dim3 grid((groups + kKnnWaves - 1) / kKnnWaves, chunks);
-        hipLaunchKernelGGL(k_knn2, grid, dim3(64 * kKnnWaves), 0, st, (const uint32_t*)d_query, n_query,
-                           (const uint32_t*)d_train, (long long)n_train, chunkLen, (long long)base_index,
-                           (orbx_match2*)d_workspace);
+        const size_t partBytes = (size_t)chunks * n_query * sizeof(orbx_match2);
+        ORBX_REQUIRE(d_workspace && workspace_bytes >= partBytes + knn2_counter_bytes(n_query),
+                     "workspace too small (%zu bytes, %zu needed on this device: ask orbx_knn2_workspace_bytes with the search's "
+                     "device current)", workspace_bytes, partBytes + knn2_counter_bytes(n_query));
+        ORBX_REQUIRE(((uintptr_t)d_workspace & 15) == 0, "workspace must be 16-byte aligned");
+        knn2_launch(d_query, n_query, d_train, n_train, base_index, chunks, (orbx_match2*)d_workspace,
+                    (int*)((char*)d_workspace + partBytes), st);
     }
     hipLaunchKernelGGL(k_knn2_merge, dim3((n_query + 3) / 4), dim3(256), 0, st, (const orbx_match2*)d_workspace, chunks,
                        n_query, d_out);
@@ -484,7 +557,16 @@ orbx_status knn_static_ptr(void** out) {
 }
 }  // namespace
 
-extern "C" size_t orbx_knn2_static_max_queries(void) { return kKnnStaticBytes / sizeof(orbx_match2); }
+// the largest n_query whose one partial row set and span counters fit the array.  Also resolves the array's address
+// on the current device (when there is one), so that a caller about to capture a graph can do that outside the capture.
+extern "C" size_t orbx_knn2_static_max_queries(void) {
+    void* warm = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) (void)knn_static_ptr(&warm);
+    size_t n = kKnnStaticBytes / sizeof(orbx_match2);
+    while (n > 0 && n * sizeof(orbx_match2) + knn2_counter_bytes((int)n) > kKnnStaticBytes) n -= 64 * kQpl;
+    return n;
+}
 
 extern "C" orbx_status orbx_hamming_knn2_device_static(const uint8_t* d_query, int n_query, const uint8_t* d_train,
                                                        int64_t n_train, int64_t base_index, orbx_match2* d_out,
@@ -495,10 +577,11 @@ extern "C" orbx_status orbx_hamming_knn2_device_static(const uint8_t* d_query, i
     ORBX_REQUIRE(base_index >= 0 && base_index + n_train <= (int64_t)INT_MAX, "train index does not fit 32 bits");
     ORBX_REQUIRE((((uintptr_t)d_query | (uintptr_t)d_train) & 15) == 0, "descriptor arrays must be 16-byte aligned");
     const size_t perChunk = (size_t)n_query * sizeof(orbx_match2);
-    ORBX_REQUIRE(perChunk <= kKnnStaticBytes,
+    const size_t counterBytes = knn2_counter_bytes(n_query);
+    ORBX_REQUIRE(perChunk + counterBytes <= kKnnStaticBytes,
                  "%d queries exceed the %zu the allocation-free search supports (its partial results live in a fixed "
                  "%zu-byte device array); use orbx_hamming_knn2_device with a workspace",
-                 n_query, kKnnStaticBytes / sizeof(orbx_match2), kKnnStaticBytes);
+                 n_query, orbx_knn2_static_max_queries(), kKnnStaticBytes);
     void* scratch = nullptr;
     orbx_status s = knn_static_ptr(&scratch);
     if (s != ORBX_OK) return s;
@@ -506,16 +589,12 @@ extern "C" orbx_status orbx_hamming_knn2_device_static(const uint8_t* d_query, i
     // as many chunks as the workspace variant would use, capped by what the array holds; the merge is
     // lexicographic on (distance, index), so the result does not depend on the number of chunks
     int chunks = 0;
-    if (n_train > 0) chunks = (int)std::min<size_t>((size_t)knn2_chunks(n_query, n_train), kKnnStaticBytes / perChunk);
-    if (chunks > 0) {
-        const long long chunkLen = (n_train + chunks - 1) / chunks;
-        const int groups = (n_query + 64 * kQpl - 1) / (64 * kQpl);
-        dim3 grid((groups + kKnnWaves - 1) / kKnnWaves, chunks);
-        hipLaunchKernelGGL(k_knn2, grid, dim3(64 * kKnnWaves), 0, st, (const uint32_t*)d_query, n_query,
-                           (const uint32_t*)d_train, (long long)n_train, chunkLen, (long long)base_index,
-                           (orbx_match2*)scratch);
-    }
-    // every partial the merge reads was written by the launch above: nothing in the array has to start at zero
+    if (n_train > 0) chunks = (int)std::min<size_t>((size_t)knn2_chunks(n_query, n_train), (kKnnStaticBytes - counterBytes) / perChunk);
+    // the span counters take the array's last bytes and are cleared on the stream before every launch (hipMemsetAsync
+    // on device memory allocates nothing); every partial the merge reads is written by the launch
+    if (chunks > 0)
+        knn2_launch(d_query, n_query, d_train, n_train, base_index, chunks, (orbx_match2*)scratch,
+                    (int*)((char*)scratch + kKnnStaticBytes - counterBytes), st);
     hipLaunchKernelGGL(k_knn2_merge, dim3((n_query + 3) / 4), dim3(256), 0, st, (const orbx_match2*)scratch, chunks,
                        n_query, d_out);
     ORBX_HIP_TRY(hipGetLastError());

@@ -52,7 +52,8 @@ def test_static_knn2_rejects_oversize_and_handles_empty():
     L = A.lib()
     dev = torch.device("cuda", 0)
     limit = L.orbx_knn2_static_max_queries()
-    assert limit == (16 << 20) // 16
+    # one partial row set (16 bytes per query) plus one span counter per 256 queries must fit the 16 MiB array
+    assert 1_000_000 < limit <= (16 << 20) // 16 and limit * 16 + (limit // 256) * 4 <= (16 << 20)
     dq = torch.zeros((8, 32), dtype=torch.uint8, device=dev)
     out = torch.zeros((8, 4), dtype=torch.int32, device=dev)
     # a query count beyond the limit is refused before any pointer is touched
@@ -66,3 +67,30 @@ def test_static_knn2_rejects_oversize_and_handles_empty():
     torch.cuda.synchronize()
     o = out.cpu().numpy()
     assert (o[:, 0] == -1).all() and (o[:, 2] == -1).all()
+
+
+def test_static_knn2_allocates_nothing_and_works_when_the_array_limits_the_workers():
+    """300 000 queries leave room for three worker row sets in the 16 MiB array, far fewer than the chip would take
+    (the merge is lexicographic, so the result does not depend on the number of workers); device memory in use is
+    the same before and after the calls."""
+    import torch
+    from orb_slam3_amd import matcher
+    A = _gpu()
+    L = A.lib()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    nq, nt = 300_000, 10_000                                     # 5 spans, 6 workers wanted, room for 3
+    dq = torch.randint(0, 256, (nq, 32), dtype=torch.uint8, device=dev, generator=g)
+    dt = torch.randint(0, 256, (nt, 32), dtype=torch.uint8, device=dev, generator=g)
+    dt[17] = dt[5]                                              # equal rows: the lower index must win
+    out_s = torch.empty((nq, 4), dtype=torch.int32, device=dev)
+    want, _ = A.knn_match2_device(dq, dt)
+    L.orbx_knn2_static_max_queries()                            # resolves the array's address outside the measured calls
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    for _ in range(2):
+        matcher.knn_match2_device_static(dq, dt, out_s)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free1 == free0, "the allocation-free search changed the device's free memory"
+    assert torch.equal(out_s, want)
