@@ -1336,6 +1336,94 @@ __device__ __forceinline__ void sincos_f32(float xf, float* s_out, float* c_out)
     *c_out = (float)c;
 }
 
+// The same value with fused multiply-adds (half the binary64 instructions; the kernels use this one).  The two
+// evaluations can differ in the last bits of the binary64 result, which the rounding to binary32 hides unless the
+// result lies within ~1e-16 (relative) of a binary32 rounding boundary: orbx_debug_sincos_diff counts the inputs
+// where that happens -- none of the 1 086 918 650 binary32 values in [0, 6.2832].
+// (a * b + c with the constant c held in a scalar register pair: left to itself the compiler spends two vector moves
+// per constant, as many vector instructions as the fusion saves)
+__device__ __forceinline__ double fma_sconst(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+__device__ __forceinline__ void sincos_f32_fma(float xf, float* s_out, float* c_out) {
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double pio2_hi = 1.57079632673412561417e+00;
+    const double pio2_lo = 6.07710050650619224932e-11;
+    const double x = (double)xf;
+    const int k = (int)fma_sconst(x, two_over_pi, 0.5);
+    const double kd = (double)k;
+    const double r = __fma_rn(kd, -pio2_lo, __fma_rn(kd, -pio2_hi, x));
+    const double z = __dmul_rn(r, r);
+    double sp = 1.0 / 355687428096000.0;
+    sp = fma_sconst(sp, z, -1.0 / 1307674368000.0);
+    sp = fma_sconst(sp, z, 1.0 / 6227020800.0);
+    sp = fma_sconst(sp, z, -1.0 / 39916800.0);
+    sp = fma_sconst(sp, z, 1.0 / 362880.0);
+    sp = fma_sconst(sp, z, -1.0 / 5040.0);
+    sp = fma_sconst(sp, z, 1.0 / 120.0);
+    sp = fma_sconst(sp, z, -1.0 / 6.0);
+    const double sn = __fma_rn(__dmul_rn(r, z), sp, r);
+    double cp = 1.0 / 20922789888000.0;
+    cp = fma_sconst(cp, z, -1.0 / 87178291200.0);
+    cp = fma_sconst(cp, z, 1.0 / 479001600.0);
+    cp = fma_sconst(cp, z, -1.0 / 3628800.0);
+    cp = fma_sconst(cp, z, 1.0 / 40320.0);
+    cp = fma_sconst(cp, z, -1.0 / 720.0);
+    cp = fma_sconst(cp, z, 1.0 / 24.0);
+    const double cs = __fma_rn(__dmul_rn(z, z), cp, __fma_rn(z, -0.5, 1.0));
+    const float snf = (float)sn, csf = (float)cs;          // (negation commutes with the rounding)
+    const bool swap = (k & 1) != 0;
+    const float s = swap ? csf : snf, c = swap ? snf : csf;
+    *s_out = (k & 2) ? -s : s;
+    *c_out = ((k + 1) & 2) ? -c : c;
+}
+
+__global__ void k_debug_sincos_diff(uint32_t firstBits, unsigned long long count, unsigned long long* nDiff, uint32_t* firstDiffs) {
+    unsigned long long local = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t bits = firstBits + (uint32_t)i;
+        const float x = __builtin_bit_cast(float, bits);
+        float s0, c0, s1, c1;
+        sincos_f32(x, &s0, &c0);
+        sincos_f32_fma(x, &s1, &c1);
+        if (__builtin_bit_cast(uint32_t, s0) != __builtin_bit_cast(uint32_t, s1) ||
+            __builtin_bit_cast(uint32_t, c0) != __builtin_bit_cast(uint32_t, c1)) {
+            const unsigned long long slot = atomicAdd(nDiff, 1ull);
+            if (slot < 16) firstDiffs[slot] = bits;
+        }
+        ++local;
+    }
+    atomicAdd(nDiff + 1, local);       // inputs compared
+}
+
+// Diagnostics: over the binary32 values with bit patterns first_bits .. first_bits + count - 1, the number of inputs for
+// which the two evaluation orders of the binary64 sine / cosine round to different binary32 values (the first 16 of
+// them in first16, the number of inputs the kernel went through in *compared).
+extern "C" long long orbx_debug_sincos_diff(uint32_t first_bits, unsigned long long count, uint32_t* first16,
+                                            unsigned long long* compared) {
+    unsigned long long* d_n = nullptr;
+    uint32_t* d_first = nullptr;
+    if (hipMalloc((void**)&d_n, 16) != hipSuccess || hipMalloc((void**)&d_first, 64) != hipSuccess) return -1;
+    hipMemset(d_n, 0, 16);
+    hipMemset(d_first, 0, 64);
+    hipLaunchKernelGGL(k_debug_sincos_diff, dim3(4096), dim3(256), 0, 0, first_bits, count, d_n, d_first);
+    const hipError_t launched = hipGetLastError(), ran = hipDeviceSynchronize();
+    if (launched != hipSuccess || ran != hipSuccess) {
+        orbx_set_error("sincos comparison kernel: %s / %s", hipGetErrorString(launched), hipGetErrorString(ran));
+        hipFree(d_n); hipFree(d_first);
+        return -1;
+    }
+    unsigned long long n[2] = {0, 0};
+    const bool ok = hipMemcpy(n, d_n, 16, hipMemcpyDeviceToHost) == hipSuccess &&
+                    (!first16 || hipMemcpy(first16, d_first, 64, hipMemcpyDeviceToHost) == hipSuccess);
+    hipFree(d_n); hipFree(d_first);
+    if (compared) *compared = n[1];
+    return ok ? (long long)n[0] : -1;
+}
+
 // Weight bytes of the orientation disc: entry [|v| * 4 + g] covers the 8 columns u = 8g - 15 .. 8g - 8 of row v as
 // { (u + 15) of the first 4 columns, 1 for the same columns, (u + 15) of the last 4, 1 for those }, a weight being 0
 // where |u| > umax[|v|] (outside the disc; u = 16 of the last group never is inside).
@@ -1375,6 +1463,152 @@ __device__ __forceinline__ constexpr uint32_t hblur_weight(int byteOffset, int d
     }
     return w;
 }
+// ======================================================================================
+// k_blur_levels: cv::GaussianBlur(7 x 7, sigma 2, BORDER_REFLECT_101) of whole pyramid levels (ORBextractor.cc:1344-1351)
+// into a second slab with the pyramid's layout, for handles whose keypoints cover their levels densely enough that
+// blurring every level once is cheaper than blurring a 37 x 37 patch per keypoint (see choose_blur_mode).
+// One wave = one tile: `nb` bands of (cw + 2) lanes; a band covers cw dword columns x stripRows rows, the bands of
+// a tile lie below each other (full-width tiles have one band of 62 columns; the narrow remainder of a level
+// stacks many short bands so that its lanes are used as well).  A lane owns 4 pixels of a row (one dword) and
+// marches down its band: the row's 7-tap horizontal sums of its 4 pixels come from its own dword and the two
+// neighbouring lanes' dwords (two DPP moves) as 10 v_dot4_u32_u8 against taps shifted to the byte position; the
+// vertical pass keeps, per pixel column, the last six sums as packed pairs of consecutive rows in registers (the row
+// loop is unrolled six times so that the ring needs no moves): three v_dot2_u32_u16 and one multiply-add per output.
+// The first and last lane of a band are halo lanes (they load and take part in the exchange, and store nothing).
+// REFLECT_101 at the level's own edge: rows by reflecting the row index, columns by a per-lane byte selector -- a
+// lane whose pixels lie beyond the edge loads the one or two dwords that hold their mirror images and one
+// v_perm_b32 puts them in place (the selector is the identity for every other lane).
+// ======================================================================================
+constexpr int kBlurTileCols = 62;       // dword columns of a full-width tile
+struct alignas(16) OrbxBlurTile {
+    int imgOff;      // byte offset of the level inside a frame's slab
+    int pitchShape;  // pitch | cw << 16 | nb << 24
+    int wh;          // width | height << 16
+    int xy;          // first stored dword column | first output row << 16
+};
+
+__device__ __forceinline__ uint32_t dpp_from_lower_lane(uint32_t v) {   // lane i receives lane i - 1's value (lane 0: zero)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t dpp_from_upper_lane(uint32_t v) {   // lane i receives lane i + 1's value (lane 63: zero)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+
+__global__ __launch_bounds__(256) void k_blur_levels(const OrbxBlurTile* __restrict__ tiles, int nTiles, int stripRows,
+                                                     const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blurred,
+                                                     long long frameStride) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= nTiles) return;
+    const OrbxBlurTile T = tiles[t];
+    const int w = T.wh & 0xFFFF, h = T.wh >> 16, pitch = T.pitchShape & 0xFFFF;
+    const int cw = (T.pitchShape >> 16) & 0xFF, nb = T.pitchShape >> 24;
+    const int col0 = T.xy & 0xFFFF, y0 = T.xy >> 16;
+    const int bandLanes = cw + 2;
+    const int bandRaw = lane / bandLanes, pos = lane - bandRaw * bandLanes;
+    const int band = min(bandRaw, nb - 1);                  // (lanes past the last band repeat it and store nothing)
+    const int c = col0 + pos - 1;                           // this lane's dword column (-1: left of the level)
+    const int yBand = y0 + band * stripRows;
+    const int lastCol = (w - 1) >> 2;
+    const uint8_t* __restrict__ src = pyr + (long long)blockIdx.y * frameStride + T.imgOff;
+    uint8_t* __restrict__ dst = blurred + (long long)blockIdx.y * frameStride + T.imgOff;
+
+    // where the lane's four pixels come from: pixel p of the level, or its mirror image
+    int q[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        int p = 4 * c + b;
+        if (p < 0) p = -p;
+        if (p >= w) p = 2 * (w - 1) - p;
+        q[b] = min(max(p, 0), w - 1);                       // (lanes far outside the level: anything in range)
+    }
+    const int qmin = min(min(q[0], q[1]), min(q[2], q[3])), qmax = max(max(q[0], q[1]), max(q[2], q[3]));
+    const int colA = qmin >> 2, colB = min(colA + 1, lastCol);
+    uint32_t sel = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) sel |= (uint32_t)((q[b] - 4 * colA) & 7) << (8 * b);    // 0..3: first dword, 4..7: second
+    const bool twoLoads = __builtin_amdgcn_readfirstlane((int)(__ballot((qmax >> 2) != colA) != 0ull)) != 0;
+    const bool stores = bandRaw < nb && pos >= 1 && pos <= cw && c <= lastCol;
+
+    uint32_t P[4][6];            // P[k][j % 6] = H_k(row j) | H_k(row j + 1) << 16, H_k = row sum of the lane's k-th pixel
+    uint32_t Hprev[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) P[k][j] = 0;
+    const us2 w0 = {18, 34}, w1 = {48, 56}, w2 = {48, 34};
+
+    // Byte offset of source row r of the lane's band (mirrored at the level's top and bottom).  Only the trips that
+    // touch the top or the bottom of the level (a wave-uniform test over all bands of the tile) pay for the mirror;
+    // the others add a scalar to the lane's first row.
+    const uint32_t plainA = (uint32_t)((yBand - 3) * pitch + 4 * colA), plainB = (uint32_t)((yBand - 3) * pitch + 4 * colB);
+    const uint32_t plainOut = (uint32_t)(yBand * pitch + 4 * c);
+    const int lastBandY = y0 + (nb - 1) * stripRows;
+    auto mirrored_row = [&](int r) {
+        int y = yBand - 3 + r;
+        y = max(y, -y);
+        y = min(y, 2 * (h - 1) - y);
+        return (uint32_t)(max(y, 0) * pitch);               // (rows far below the level: stored nowhere)
+    };
+    // The six rows of a trip are loaded one trip ahead of their use: a wave waits for memory once per trip, with a
+    // trip's arithmetic in between, instead of once per row.
+    uint32_t curA[6], curB[6], nxtA[6], nxtB[6];
+    auto load_trip = [&](int rBase, uint32_t (&A)[6], uint32_t (&B)[6]) {
+        const bool edge = y0 - 3 + rBase < 0 || lastBandY - 3 + rBase + 5 >= h;          // wave-uniform
+        if (edge) {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const uint32_t ro = mirrored_row(rBase + u);
+                A[u] = *reinterpret_cast<const uint32_t*>(src + (ro + 4u * (uint32_t)colA));
+                B[u] = twoLoads ? *reinterpret_cast<const uint32_t*>(src + (ro + 4u * (uint32_t)colB)) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const uint32_t so = (uint32_t)((rBase + u) * pitch);                       // scalar
+                A[u] = *reinterpret_cast<const uint32_t*>(src + (plainA + so));
+                B[u] = twoLoads ? *reinterpret_cast<const uint32_t*>(src + (plainB + so)) : 0u;
+            }
+        }
+    };
+    load_trip(0, curA, curB);
+    const int trips = stripRows / 6 + 1;                    // stripRows + 6 source rows (stripRows is a multiple of 6)
+    for (int r6 = 0; r6 < trips; ++r6) {
+        load_trip(6 * (r6 + 1), nxtA, nxtB);                // (one trip past the end: mirrored or clamped rows, unused)
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int r = 6 * r6 + u;
+            const uint32_t C = __builtin_amdgcn_perm(curB[u], curA[u], sel);   // (the identity wherever one load suffices)
+            const uint32_t L = dpp_from_lower_lane(C), R = dpp_from_upper_lane(C);
+            // horizontal sums of the lane's 4 pixels: the window of pixel k starts at byte k + 1 of (L, C, R)
+            uint32_t H[4];
+            H[0] = __builtin_amdgcn_udot4(C, hblur_weight(1, 1), __builtin_amdgcn_udot4(L, hblur_weight(1, 0), 0u, false), false);
+            H[1] = __builtin_amdgcn_udot4(R, hblur_weight(2, 2), __builtin_amdgcn_udot4(C, hblur_weight(2, 1), __builtin_amdgcn_udot4(L, hblur_weight(2, 0), 0u, false), false), false);
+            H[2] = __builtin_amdgcn_udot4(R, hblur_weight(3, 2), __builtin_amdgcn_udot4(C, hblur_weight(3, 1), __builtin_amdgcn_udot4(L, hblur_weight(3, 0), 0u, false), false), false);
+            H[3] = __builtin_amdgcn_udot4(R, hblur_weight(0, 1), __builtin_amdgcn_udot4(C, hblur_weight(0, 0), 0u, false), false);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) P[k][(u + 5) % 6] = Hprev[k] | (H[k] << 16);      // rows r - 1, r
+            if (r6 > 0) {
+                const int yo = yBand + r - 6;                // source rows r - 6 .. r give output row yo
+                uint32_t o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t a = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, P[k][u]), w0, __umul24(H[k], 18u) + 32768u, false);
+                    a = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, P[k][(u + 2) % 6]), w1, a, false);
+                    o[k] = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, P[k][(u + 4) % 6]), w2, a, false);
+                }
+                // bytes 2 of the four sums (sum >> 16 < 256)
+                const uint32_t out4 = __builtin_amdgcn_perm(o[1], o[0], 0x0c0c0602u) | __builtin_amdgcn_perm(o[3], o[2], 0x06020c0cu);
+                if (stores && yo < h) *reinterpret_cast<uint32_t*>(dst + (plainOut + (uint32_t)((r - 6) * pitch))) = out4;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Hprev[k] = H[k];
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) { curA[u] = nxtA[u]; curB[u] = nxtB[u]; }
+    }
+}
+
 template <int OX>
 __device__ __forceinline__ void hblur_rows(const uint8_t* __restrict__ rawBase, uint32_t* __restrict__ hor, int lane) {
     constexpr int kRowPairs = (kRawW + 1) / 2;       // 22
@@ -1399,6 +1633,60 @@ __device__ __forceinline__ void hblur_rows(const uint8_t* __restrict__ rawBase, 
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if (c0 + k < kBlurW) dst[k * kHorTPD] = sums[0][k] | (sums[1][k] << 16);     // a row sum is < 65536
+    }
+}
+
+// Steered BRIEF (ORBextractor.cc:139-179) over a blurred patch in LDS and the keypoint's output record: lane handles
+// comparisons 4 lane .. 4 lane + 3.  patch[(18 + rx) * SX + (18 + ry) * SY] is the blurred pixel (rx, ry) from the keypoint.
+template <int SX, int SY>
+__device__ __forceinline__ void steered_brief_store(const uint8_t* __restrict__ patch, float angle, int lane,
+                                                    const OrbxFrameGeo* __restrict__ geo, const OrbxDescWork& W, int frame,
+                                                    int capacity, orbx_keypoint* __restrict__ outKps,
+                                                    uint8_t* __restrict__ outDesc) {
+    const float deg2rad = (float)(3.14159265358979323846 / 180.f);
+    float a, b;
+    sincos_f32_fma(__fmul_rn(angle, deg2rad), &b, &a);   // (equal to sincos_f32 on every binary32 input in [0, 2 pi])
+    // the lane's 8 sample points = 16 consecutive floats of the pattern table.  Both rotated coordinates of a point
+    // come from packed binary32 operations (each product and sum rounded on its own, as in the scalar reference), and
+    // adding 1.5 * 2^23 + 18 rounds to the nearest-even integer and leaves (coordinate + 18) in the low mantissa bits.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const float4* patp = reinterpret_cast<const float4*>(c_patternF + 16 * lane);
+    const float4 pq[4] = {patp[0], patp[1], patp[2], patp[3]};
+    const f2 ba = {b, a}, anb = {a, -b};
+    const float magic = 12582912.0f + (float)kBlurR;
+    uint32_t nib = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float pts[4] = {pq[j].x, pq[j].y, pq[j].z, pq[j].w};
+        int t[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float px = pts[2 * e], py = pts[2 * e + 1];
+            const f2 u = f2{px, px} * ba;                 // (px b, px a)
+            const f2 w = f2{py, py} * anb;                // (py a, -(py b)): the sign change is exact
+            const f2 r = u + w;                           // (ry, rx) = (px b + py a, px a - py b)
+            // (scalar adds on purpose: with the sum written as a 2-vector this compiler folded both lanes into one)
+            const float my = r[0] + magic, mx = r[1] + magic;
+            const uint32_t iy = __builtin_bit_cast(uint32_t, my) & 0xFFFFu, ix = __builtin_bit_cast(uint32_t, mx) & 0xFFFFu;
+            t[e] = patch[ix * SX + iy * SY];
+        }
+        nib |= (uint32_t)(t[0] < t[1]) << j;
+    }
+    const uint32_t other = __shfl_xor(nib, 1);
+    const long long row = (long long)frame * capacity + (W.slotLevel & 0xFFFFFF);
+    if ((lane & 1) == 0) outDesc[row * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
+    if (lane == 0) {
+        const int level = W.slotLevel >> 24;
+        const OrbxLevelGeo& L = geo->lv[level];
+        orbx_keypoint k;
+        k.x = W.x; k.y = W.y;
+        if (level != 0) { k.x = __fmul_rn(W.x, L.scale); k.y = __fmul_rn(W.y, L.scale); }
+        k.size = L.patchSize;
+        k.angle = angle;
+        k.response = W.response;
+        k.octave = level;
+        k.class_id = -1;
+        outKps[row] = k;
     }
 }
 
@@ -1547,53 +1835,101 @@ __global__ __launch_bounds__(64 * kDescWaves) void k_describe(const OrbxFrameGeo
     ORBX_DESC_PHASE_END(4, blur[lane * 23] + (int)angle);
 
     if (!active) return;
-    // ---- steered BRIEF: lane handles comparisons 4*lane .. 4*lane+3 ----
-    const float deg2rad = (float)(3.14159265358979323846 / 180.f);
-    float a, b;
-    sincos_f32(__fmul_rn(angle, deg2rad), &b, &a);
-    // the lane's 8 sample points = 16 consecutive floats of the pattern table.  Both rotated coordinates of a point
-    // come from packed binary32 operations (each product and sum rounded on its own, as in the scalar reference), and
-    // adding 1.5 * 2^23 + 18 rounds to the nearest-even integer and leaves (coordinate + 18) in the low mantissa bits.
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const float4* patp = reinterpret_cast<const float4*>(c_patternF + 16 * lane);
-    const float4 pq[4] = {patp[0], patp[1], patp[2], patp[3]};
-    const f2 ba = {b, a}, anb = {a, -b};
-    const float magic = 12582912.0f + (float)kBlurR;
-    uint32_t nib = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float pts[4] = {pq[j].x, pq[j].y, pq[j].z, pq[j].w};
-        int t[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float px = pts[2 * e], py = pts[2 * e + 1];
-            const f2 u = f2{px, px} * ba;                 // (px b, px a)
-            const f2 w = f2{py, py} * anb;                // (py a, -(py b)): the sign change is exact
-            const f2 r = u + w;                           // (ry, rx) = (px b + py a, px a - py b)
-            // (scalar adds on purpose: with the sum written as a 2-vector this compiler folded both lanes into one)
-            const float my = r[0] + magic, mx = r[1] + magic;
-            const uint32_t iy = __builtin_bit_cast(uint32_t, my) & 0xFFFFu, ix = __builtin_bit_cast(uint32_t, mx) & 0xFFFFu;
-            t[e] = blur[ix * kBlurP + iy];                // transposed core: [kBlurR + rx][kBlurR + ry]
-        }
-        nib |= (uint32_t)(t[0] < t[1]) << j;
-    }
-    const uint32_t other = __shfl_xor(nib, 1);
-    const long long row = (long long)frame * capacity + G.slot;
-    if ((lane & 1) == 0) outDesc[row * 32 + (lane >> 1)] = (uint8_t)(nib | (other << 4));
-    if (lane == 0) {
-        const int level = W.slotLevel >> 24;
-        const OrbxLevelGeo& L = geo->lv[level];
-        orbx_keypoint k;
-        k.x = W.x; k.y = W.y;
-        if (level != 0) { k.x = __fmul_rn(W.x, L.scale); k.y = __fmul_rn(W.y, L.scale); }
-        k.size = L.patchSize;
-        k.angle = angle;
-        k.response = W.response;
-        k.octave = level;
-        k.class_id = -1;
-        outKps[row] = k;
-    }
+    steered_brief_store<kBlurP, 1>(blur, angle, lane, geo, W, frame, capacity, outKps, outDesc);
     ORBX_DSTAMP(4);   // steered tests + output
+}
+
+// k_describe_pre: k_describe for a handle whose levels k_blur_levels has blurred already.  Orientation straight from
+// the level image (item = row v, group of 8 columns: one 12-byte load, two byte windows, four dot products -- the
+// raw patch never goes through LDS); the 37 x 37 blurred patch is fetched into LDS as 16-byte chunks and sampled.
+template <int kWaves>
+__global__ __launch_bounds__(64 * kWaves) void k_describe_pre(const OrbxFrameGeo* __restrict__ geo, const uint8_t* __restrict__ pyr,
+                                                     const uint8_t* __restrict__ blurred, long long frameStride,
+                                                     const OrbxDescWork* __restrict__ work, int kpTotal,
+                                                     unsigned int frameMagic, const int* __restrict__ counts,
+                                                     orbx_keypoint* __restrict__ outKps, uint8_t* __restrict__ outDesc,
+                                                     int capacity) {
+    constexpr int kPatP = 48;                                        // LDS pitch of the blurred patch: three 16-byte chunks
+    __shared__ __align__(16) uint8_t s_patches[kWaves][kBlurW * kPatP + 16];
+    const int logicalBlock = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int frame = frameMagic ? (int)__umulhi((unsigned int)logicalBlock, frameMagic) : logicalBlock / (int)gridDim.x;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    uint8_t* s_patch = s_patches[wv];                                // nothing is shared between the waves of a workgroup
+    const int ordinal = (logicalBlock - frame * gridDim.x) * kWaves + wv;
+    if (ordinal >= counts[2 * frame]) return;
+    const OrbxDescWork W = work[(long long)frame * kpTotal + ordinal];
+    const int w = W.wh & 0xFFFF, h = W.wh >> 16, pitch = W.pitch;
+    const long long imgOff = (long long)frame * frameStride + W.imgOff;
+    const uint8_t* __restrict__ img = pyr + imgOff;
+    const uint8_t* __restrict__ bimg = blurred + imgOff;
+    const int cx = W.cxy & 0xFFFF, cy = W.cxy >> 16;
+
+    // ---- the blurred patch: rows cy-18 .. cy+18, columns from the 4-byte aligned xa <= cx-18 (a chunk may reach past
+    // the row's pitch into the next row or, for a frame's last row, the next frame or the slab's padding: loaded, never
+    // sampled).  A patch that crosses the level's edge takes the byte path: the blur of the mirrored image is the
+    // mirror image of the blur.
+    struct __attribute__((packed, aligned(4))) Chunk16 { uint32_t a, b, c, d; };
+    const int px0 = cx - kBlurR, py0 = cy - kBlurR;
+    const int xa = px0 & ~3;
+    const bool interior = px0 >= 0 && py0 >= 0 && cx + kBlurR < w && cy + kBlurR < h;
+    const int ox = interior ? px0 - xa : 0;
+    if (interior) {
+        Chunk16 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = lane + 64 * u, r = i / 3, d = i - 3 * r;
+            if (i < kBlurW * 3) v[u] = *reinterpret_cast<const Chunk16*>(bimg + (long long)(py0 + r) * pitch + xa + 16 * d);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = lane + 64 * u, r = i / 3, d = i - 3 * r;
+            if (i < kBlurW * 3) *reinterpret_cast<uint4*>(s_patch + r * kPatP + 16 * d) = make_uint4(v[u].a, v[u].b, v[u].c, v[u].d);
+        }
+    } else {
+        for (int i = lane; i < kBlurW * kBlurW; i += 64) {
+            const int r = i / kBlurW, c = i - r * kBlurW;
+            const int yy = reflect101_dev(py0 + r, h), xx = reflect101_dev(px0 + c, w);
+            s_patch[r * kPatP + c] = bimg[(long long)yy * pitch + xx];
+        }
+    }
+
+    // ---- orientation (ORBextractor.cc:90-137): m10 = sum u I, m01 = sum v I over the radius-15 disc ----
+    int m10 = 0, m01 = 0;
+    const int ux0 = cx - 15;
+    const bool discInside = ux0 >= 0 && cy - 15 >= 0 && cx + 15 < w && cy + 15 < h;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = lane + 64 * it;
+        if (i < 31 * 4) {
+            const int row = i >> 2, g = i & 3;
+            const int v = row - 15, av = v < 0 ? -v : v;
+            const uint4 wt = *reinterpret_cast<const uint4*>(&c_orientW.w[4 * (av * 4 + g)]);
+            uint32_t pa, pb;
+            if (discInside) {
+                struct __attribute__((packed, aligned(4))) Chunk12 { uint32_t a, b, c; };
+                const int b0 = ux0 + 8 * g;                      // first of the item's 8 columns
+                const Chunk12 d = *reinterpret_cast<const Chunk12*>(img + (long long)(cy + v) * pitch + (b0 & ~3));
+                pa = __builtin_amdgcn_alignbyte(d.b, d.a, b0 & 3);
+                pb = __builtin_amdgcn_alignbyte(d.c, d.b, b0 & 3);
+            } else {
+                pa = pb = 0;
+                const int yy = reflect101_dev(cy + v, h);
+                for (int k = 0; k < 4; ++k) {
+                    pa |= (uint32_t)img[(long long)yy * pitch + reflect101_dev(ux0 + 8 * g + k, w)] << (8 * k);
+                    pb |= (uint32_t)img[(long long)yy * pitch + reflect101_dev(ux0 + 8 * g + 4 + k, w)] << (8 * k);
+                }
+            }
+            const int sumI = (int)__builtin_amdgcn_udot4(pb, wt.w, __builtin_amdgcn_udot4(pa, wt.y, 0u, false), false);
+            const int sumUI = (int)__builtin_amdgcn_udot4(pb, wt.z, __builtin_amdgcn_udot4(pa, wt.x, 0u, false), false);
+            m10 += sumUI - 15 * sumI;
+            m01 += v * sumI;
+        }
+    }
+    m10 = wave_sum_i32(m10);
+    m01 = wave_sum_i32(m01);
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the wave's own LDS writes: wave order is enough
+    steered_brief_store<1, kPatP>(s_patch + ox, angle, lane, geo, W, frame, capacity, outKps, outDesc);
 }
 
 // ======================================================================================
@@ -1623,6 +1959,11 @@ struct orbx_extractor {
     orbx_rect* d_rects = nullptr;
     OrbxFastCell* d_cells = nullptr;   // FAST cell table
     OrbxDescWork* d_descWork = nullptr;   // per frame: k_layout's records for k_describe
+    // whole-level blur (k_blur_levels + k_describe_pre) instead of a blur per keypoint patch: see choose_blur_mode
+    bool levelBlur = false;
+    uint8_t* d_blur = nullptr;            // the blurred pyramid: max_batch slabs with the pyramid's layout
+    OrbxBlurTile* d_blurTiles = nullptr;
+    int nBlurTiles = 0, blurStripRows = 36;
     int *d_xofs = nullptr, *d_yofs = nullptr;
     uint32_t *d_xcoef = nullptr, *d_ycoef = nullptr;
     size_t tapAlloc = 0;
@@ -1713,6 +2054,47 @@ static void free_geo_buffers(orbx_extractor* ex) {
     hipFree(ex->d_ycoef); ex->d_ycoef = nullptr;
     hipFree(ex->d_cells); ex->d_cells = nullptr;
     hipFree(ex->d_descWork); ex->d_descWork = nullptr;
+    hipFree(ex->d_blur); ex->d_blur = nullptr;
+    hipFree(ex->d_blurTiles); ex->d_blurTiles = nullptr;
+}
+
+// Whether a handle blurs whole levels once (k_blur_levels, then k_describe_pre samples them) or every keypoint's
+// 37 x 37 patch on its own (k_describe).  The level blur costs per pixel of the pyramid, the patch blur per keypoint:
+// the break-even, measured on an MI355X at 64 frames a batch, lies near one keypoint per kBlurBreakEvenPixels pixels
+// of level 0.  ORBX_BLUR_MODE=patch|level overrides the choice (for measurements).
+constexpr int kBlurBreakEvenPixels = 300;
+static bool choose_blur_mode(const orbx_params& P, int w, int h) {
+    if (const char* e = getenv("ORBX_BLUR_MODE")) {
+        if (!strcmp(e, "patch")) return false;
+        if (!strcmp(e, "level")) return true;
+    }
+    return (long long)P.nfeatures * kBlurBreakEvenPixels >= (long long)w * h;
+}
+
+// The tiles of k_blur_levels for one frame: per level, full-width tiles of 62 dword columns x one strip of rows, and
+// for the columns left over a tile of stacked bands (as many as fit 64 lanes).
+static std::vector<OrbxBlurTile> blur_tiles(const OrbxFrameGeo& g, int stripRows) {
+    std::vector<OrbxBlurTile> tiles;
+    for (int l = 0; l < g.nlevels; ++l) {
+        const OrbxLevelGeo& L = g.lv[l];
+        const int D = ((L.w - 1) >> 2) + 1, full = D / kBlurTileCols, rem = D - full * kBlurTileCols;
+        auto add = [&](int col0, int cw, int nb, int y0) {
+            OrbxBlurTile T;
+            T.imgOff = (int)L.off;
+            T.pitchShape = L.pitch | (cw << 16) | (nb << 24);
+            T.wh = L.w | (L.h << 16);
+            T.xy = col0 | (y0 << 16);
+            tiles.push_back(T);
+        };
+        for (int y0 = 0; y0 < L.h; y0 += stripRows)
+            for (int j = 0; j < full; ++j) add(j * kBlurTileCols, kBlurTileCols, 1, y0);
+        if (rem > 0) {
+            const int bands = 64 / (rem + 2);
+            for (int y0 = 0; y0 < L.h; y0 += stripRows * bands)
+                add(full * kBlurTileCols, rem, std::min(bands, (L.h - y0 + stripRows - 1) / stripRows), y0);
+        }
+    }
+    return tiles;
 }
 
 // Computes the level / cell / quadtree geometry for a w x h image and (re)allocates the
@@ -1887,6 +2269,19 @@ static orbx_status setup_geometry(orbx_extractor* ex, int w, int h) {
         ORBX_HIP_TRY(hipMemcpy(ex->d_cells, cells.data(), cells.size() * sizeof(OrbxFastCell), hipMemcpyHostToDevice));
         // k_layout's records for k_describe: one per keypoint record of a frame
         ORBX_HIP_TRY(hipMalloc((void**)&ex->d_descWork, B * (size_t)std::max(g.kpTotal, 1) * sizeof(OrbxDescWork)));
+    }
+    ex->levelBlur = choose_blur_mode(P, w, h);
+    if (ex->levelBlur) {
+        ORBX_REQUIRE(g.pyrBytes < (1ll << 31), "pyramid slab of one frame exceeds 2 GiB");
+        if (const char* e = getenv("ORBX_BLUR_STRIP_ROWS")) {
+            const int v = atoi(e);
+            if (v >= 6 && v <= 1200 && v % 6 == 0) ex->blurStripRows = v;
+        }
+        const std::vector<OrbxBlurTile> tiles = blur_tiles(g, ex->blurStripRows);
+        ex->nBlurTiles = (int)tiles.size();
+        ORBX_HIP_TRY(hipMalloc((void**)&ex->d_blur, B * (size_t)g.pyrBytes + 256));
+        ORBX_HIP_TRY(hipMalloc((void**)&ex->d_blurTiles, tiles.size() * sizeof(OrbxBlurTile)));
+        ORBX_HIP_TRY(hipMemcpy(ex->d_blurTiles, tiles.data(), tiles.size() * sizeof(OrbxBlurTile), hipMemcpyHostToDevice));
     }
     ORBX_HIP_TRY(hipMemcpy(ex->d_geo, &g, sizeof(g), hipMemcpyHostToDevice));
     ex->geo = g;
@@ -2096,7 +2491,15 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
     const unsigned int descGrid = (unsigned int)((std::min(g.kpTotal, capacity) + kDescWaves - 1) / kDescWaves);
     const unsigned int frameMagic =
         ((unsigned long long)descGrid * nf) * descGrid < (1ull << 32) && descGrid > 1 ? (unsigned int)((1ull << 32) / descGrid) + 1u : 0u;
-    if (descGrid > 0)
+    if (descGrid > 0 && ex->levelBlur) {
+        uint8_t* blurView = ex->d_blur + (size_t)frame0 * g.pyrBytes;
+        hipLaunchKernelGGL(k_blur_levels, dim3((ex->nBlurTiles + 3) / 4, nf), dim3(256), 0, st, ex->d_blurTiles, ex->nBlurTiles,
+                           ex->blurStripRows, V.d_pyr, blurView, g.pyrBytes);
+        // (one wave per workgroup, as for k_describe: 2, 4 and 8 waves measured within 3 % of it)
+        static_assert(kDescWaves == 1, "k_describe_pre shares k_describe's grid: one keypoint per workgroup");
+        hipLaunchKernelGGL(k_describe_pre<1>, dim3(descGrid, nf), dim3(64), 0, st, ex->d_geo, V.d_pyr, blurView, g.pyrBytes,
+                           V.d_descWork, g.kpTotal, frameMagic, d_counts, d_kps, d_desc, capacity);
+    } else if (descGrid > 0)
         hipLaunchKernelGGL(k_describe, dim3(descGrid, nf), dim3(64 * kDescWaves), 0, st, ex->d_geo, V.d_pyr, g.pyrBytes,
                            V.d_descWork, g.kpTotal, frameMagic, d_counts, d_kps, d_desc, capacity);
     mark(ex, st);

@@ -19,6 +19,15 @@ def _gpu():
     return A
 
 
+@pytest.fixture(autouse=True, params=["patch", "level"])
+def blur_mode(request, monkeypatch):
+    """Every test of this file runs twice: with the Gaussian blur computed per keypoint patch inside the descriptor
+    kernel, and with whole levels blurred by a kernel of their own (the library picks one per handle by keypoint
+    density; ORBX_BLUR_MODE, read when a handle lays out its buffers, forces it)."""
+    monkeypatch.setenv("ORBX_BLUR_MODE", request.param)
+    return request.param
+
+
 def _same(ka, da, ma, kb, db, mb):
     assert ma == mb
     assert len(ka) == len(kb)

@@ -59,7 +59,11 @@
     X(48, "v_perm_b32", "v_perm_b32 %0, %0, %0, %0")                    \
     X(49, "v_alignbyte_b32", "v_alignbyte_b32 %0, %0, %0, 1")           \
     X(50, "v_pk_mul_f32", "v_pk_mul_f32 %0, %0, %0")                    \
-    X(51, "v_pk_add_f32", "v_pk_add_f32 %0, %0, %0")
+    X(51, "v_pk_add_f32", "v_pk_add_f32 %0, %0, %0")                    \
+    X(52, "v_fma_f64", "v_fma_f64 %0, %0, %0, %0")                      \
+    X(53, "v_mul_f64", "v_mul_f64 %0, %0, %0")                          \
+    X(54, "v_add_f64", "v_add_f64 %0, %0, %0")                          \
+    X(55, "v_pk_fma_f32", "v_pk_fma_f32 %0, %0, %0, %0")
 
 // Operand kinds: %1 is a second vector register, %2 a scalar register.
 #define ROWS2(X)                                                        \
