@@ -2059,10 +2059,13 @@ static void free_geo_buffers(orbx_extractor* ex) {
 }
 
 // Whether a handle blurs whole levels once (k_blur_levels, then k_describe_pre samples them) or every keypoint's
-// 37 x 37 patch on its own (k_describe).  The level blur costs per pixel of the pyramid, the patch blur per keypoint:
-// the break-even, measured on an MI355X at 64 frames a batch, lies near one keypoint per kBlurBreakEvenPixels pixels
-// of level 0.  ORBX_BLUR_MODE=patch|level overrides the choice (for measurements).
-constexpr int kBlurBreakEvenPixels = 300;
+// 37 x 37 patch on its own (k_describe).  The level blur costs per pixel of the pyramid and is bound by memory
+// bandwidth (it reads and writes every level), the patch blur costs instructions per keypoint.  Measured on an MI355X
+// with 752 x 480 images, 64 frames a launch: one launch at a time the two are equal near one keypoint per 300 pixels
+// of level 0; with several streams keeping the chip full (where the level blur's memory traffic competes with the
+// other kernels) near one per 140 pixels -- 2500 keypoints a frame -- and at 5000 the level blur is 12 % ahead.  The
+// second figure decides.  ORBX_BLUR_MODE=patch|level overrides the choice (for measurements).
+constexpr int kBlurBreakEvenPixels = 140;
 static bool choose_blur_mode(const orbx_params& P, int w, int h) {
     if (const char* e = getenv("ORBX_BLUR_MODE")) {
         if (!strcmp(e, "patch")) return false;
