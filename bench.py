@@ -149,6 +149,51 @@ def pick_concurrent_stream(torch, dev, chosen, candidates=6, cycles=200000):
     return best_s, best_r
 
 
+def map_shard(rank, world, total):
+    """Rows [base, base + n_local) of the map that rank `rank` of `world` holds: equal contiguous shards, the last rank
+    takes the remainder."""
+    shard = total // world
+    base = rank * shard
+    return base, (shard if rank < world - 1 else total - base)
+
+
+def pair_seed(rank, i):
+    """Seed of stereo pair i of a rank's batch (distinct across ranks while a batch has fewer than 100000 pairs)."""
+    return 100000 * (rank + 1) + i
+
+
+def dry_world(A, torch, dev, world, batch, n_map=200_003, n_query=1000):
+    """Every rank-dependent piece of arithmetic of the world > 1 branches, run rank by rank on ONE GPU: the map shards
+    (same seeds, same base / n_local as the real ranks would use, at a reduced map size with a remainder for the last
+    rank), each shard searched with its base index, the partial top-2 rows stacked as an all-gather would deliver them
+    and merged with knn2_merge_device, compared with one search over the whole map; and the per-rank frame seeds.
+    No collective runs: what this checks is the sharding, not RCCL."""
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    dq = torch.randint(0, 256, (n_query, 32), dtype=torch.uint8, device=dev, generator=g)
+    shards, parts, covered = [], [], 0
+    for r in range(world):
+        base, n_local = map_shard(r, world, n_map)
+        assert base == covered and n_local >= 0, "shards must tile the map in rank order"
+        covered += n_local
+        g2 = torch.Generator(device=dev); g2.manual_seed(600 + r)
+        shard = torch.randint(0, 256, (n_local, 32), dtype=torch.uint8, device=dev, generator=g2)
+        if r == world - 1 and n_local > 3:
+            shard[n_local - 1] = shards[0][0] if shards else shard[0]      # a duplicate across ranks: the lower global index wins
+        shards.append(shard)
+        p, _ = A.knn_match2_device(dq, shard, base_index=base)
+        parts.append(p.clone())
+    assert covered == n_map
+    merged = A.knn2_merge_device(torch.stack(parts))
+    whole, _ = A.knn_match2_device(dq, torch.cat(shards), base_index=0)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(merged, whole))
+    seeds = [pair_seed(r, i) for r in range(world) for i in range(batch)]
+    return {"world": world, "map_rows": n_map, "queries": n_query,
+            "shards": [list(map_shard(r, world, n_map)) for r in range(world)],
+            "merged_equals_unsharded": same, "frame_seeds_distinct": len(set(seeds)) == len(seeds),
+            "note": "rank-by-rank on one GPU; no collective involved"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +206,8 @@ def main():
     ap.add_argument("--no-1080p", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--batch-1080p", type=int, default=32, help="1920x1080 frames per launch per GPU")
+    ap.add_argument("--dry-world", type=int, default=0,
+                    help="N > 1: check the sharding arithmetic of an N-rank run rank by rank on this GPU, print it and exit")
     args = ap.parse_args()
 
     import torch
@@ -181,6 +228,12 @@ def main():
     # the interpreter's first full garbage collection (35-45 ms over what the imports leave behind) happens here, not
     # inside a timed call (it used to hit one extraction call per process: profiles/r03_slow_call_gc_probe.txt)
     A.settle_interpreter()
+
+    if args.dry_world > 1:
+        assert world == 1, "--dry-world runs in a single process"
+        d = dry_world(A, torch, dev, args.dry_world, args.batch)
+        print(json.dumps({"dry_world": d}))
+        sys.exit(0 if d["merged_equals_unsharded"] and d["frame_seeds_distinct"] else 1)
 
     host_path = None
     # --- the host entry points: pageable image in, keypoints / descriptors in host memory out (PCIe inclusive).
@@ -236,7 +289,7 @@ def main():
 
     B = args.batch
     # B distinct stereo pairs per rank (seeded)
-    pairs = [synth.stereo_pair(W, H, 100000 * (rank + 1) + i) for i in range(B)]
+    pairs = [synth.stereo_pair(W, H, pair_seed(rank, i)) for i in range(B)]
     left = np.stack([p[0] for p in pairs])
     right = np.stack([p[1] for p in pairs])
     del pairs
@@ -530,9 +583,7 @@ def main():
     if not args.no_hamming:
         g = torch.Generator(device=dev); g.manual_seed(5)
         dq = torch.randint(0, 256, (NQ_MAP, 32), dtype=torch.uint8, device=dev, generator=g)
-        shard = NT_MAP // world
-        base = rank * shard
-        n_local = shard if rank < world - 1 else NT_MAP - base
+        base, n_local = map_shard(rank, world, NT_MAP)
         g2 = torch.Generator(device=dev); g2.manual_seed(600 + rank)
         dt_map = torch.randint(0, 256, (n_local, 32), dtype=torch.uint8, device=dev, generator=g2)
         part = torch.empty((NQ_MAP, 4), dtype=torch.int32, device=dev)

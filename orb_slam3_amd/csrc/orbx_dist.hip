@@ -55,6 +55,11 @@ extern "C" orbx_status orbx_hamming_knn2_sharded_device(const uint8_t* d_query, 
     orbx_match2* local = reinterpret_cast<orbx_match2*>(ws);
     orbx_match2* parts = reinterpret_cast<orbx_match2*>(ws + rows);
     char* inner = ws + rows + align256(rows * (size_t)world);
+    // Everything that depends on the arguments has been checked above, before anything is enqueued: from here on the
+    // local search can only fail with a HIP error.  A rank to which that happens returns without entering the
+    // all-gather, and the other ranks wait in it -- as after any failed rank of a collective, the caller has to tear
+    // the communicator down (ncclCommAbort / orbx_rccl_comm_destroy) on all ranks.
+    DIST_REQUIRE(n_train_shard == 0 || d_train_shard, "null shard of %lld rows", (long long)n_train_shard);
     orbx_status s = orbx_hamming_knn2_device(d_query, n_query, d_train_shard, n_train_shard, base_index, local, inner,
                                              workspace_bytes - (size_t)(inner - ws), stream);
     if (s != ORBX_OK) return s;

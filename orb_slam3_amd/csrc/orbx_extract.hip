@@ -438,12 +438,17 @@ extern "C" int orbx_debug_desc_stamps(unsigned long long* out8, int reset) {
 #endif
 // Diagnostic builds only (-DORBX_FAST_STOP=n / -DORBX_DESC_STOP=n): the kernel ends after its n-th phase, so that the
 // instruction counters of successive builds differ by exactly one phase.  Results are meaningless in such a build.
-#ifdef ORBX_FAST_STOP
+// (-DORBX_ISA_MARKERS, assembly listings only: a comment line at every phase boundary, for tools/isa_phase_table.py)
+#if defined(ORBX_ISA_MARKERS)
+#define ORBX_FAST_PHASE_END(n) asm volatile("; orbx-phase-end fast " #n ::: "memory")
+#elif defined(ORBX_FAST_STOP)
 #define ORBX_FAST_PHASE_END(n) do { if (ORBX_FAST_STOP == (n)) return; } while (0)
 #else
 #define ORBX_FAST_PHASE_END(n) do {} while (0)
 #endif
-#ifdef ORBX_DESC_STOP
+#if defined(ORBX_ISA_MARKERS)
+#define ORBX_DESC_PHASE_END(n, value) asm volatile("; orbx-phase-end describe " #n ::: "memory")
+#elif defined(ORBX_DESC_STOP)
 // (the value keeps what the phases so far have produced alive: without a consumer the compiler drops them)
 #define ORBX_DESC_PHASE_END(n, value) do { if (ORBX_DESC_STOP == (n)) { if (active) outDesc[((long long)frame * capacity + G.slot) * 32 + (lane & 31)] = (uint8_t)(value); return; } } while (0)
 #else
@@ -452,6 +457,13 @@ extern "C" int orbx_debug_desc_stamps(unsigned long long* out8, int reset) {
 
 // kP = LDS tile pitch known at compile time (row steps and the 3-row look-ahead become
 // immediate offsets), or 0 to take it from the geometry.
+// Diagnostic build only (-DORBX_EXTRA_SALU=n): n more scalar moves in every row step of the quick reject, to see
+// how the kernel's time follows its scalar instruction count (tools/extra_salu.sh).
+#ifdef ORBX_EXTRA_SALU
+#define ORBX_EXTRA_SALU_PER_ROW { int sdummy; _Pragma("unroll") for (int e = 0; e < ORBX_EXTRA_SALU; ++e) asm volatile("s_mov_b32 %0, 0x1234" : "=s"(sdummy)); }
+#else
+#define ORBX_EXTRA_SALU_PER_ROW
+#endif
 template <int kP>
 __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __restrict__ geo,
                                                        const OrbxFastCell* __restrict__ cells,
@@ -645,6 +657,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
                     const uint32_t dk = ((Cd - nU) | (Cd - nD)) & ((Cd - nL) | (Cd - nR)) &                 \
                                         ((Cd - nA) | (Cd - nB)) & ((Cd - nP) | (Cd - nQ));                  \
                     mask = (mask >> 1) | ((br | dk) & valid);                                               \
+                    ORBX_EXTRA_SALU_PER_ROW                                                                 \
                     c += PD;                                                                                \
                     C##i0 = c[3 * PD]; L##i0 = c[3 * PD + dl]; R##i0 = c[3 * PD + dr];                      \
                 }

@@ -1,11 +1,14 @@
 // The multi-GPU entry points of include/orbx_dist.h on however many GPUs the machine shows (one on the test box):
 // the sharded k = 2 search through a real RCCL communicator of one rank, split into two calls' worth of shards by
-// hand to exercise base_index, and the extractor pool against a single extractor.  Prints one line per check.
+// hand to exercise base_index; with two or more GPUs the same search with one rank (thread) per device; and the
+// extractor pool (all devices) against a single extractor.  Prints one line per check.
 #include <hip/hip_runtime_api.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "orbx_dist.h"
@@ -34,6 +37,85 @@ static std::vector<uint8_t> scene(int w, int h, int salt) {
             for (int x = x0; x < x0 + rw && x < w; ++x) img[(size_t)y * w + x] = v;
     }
     return img;
+}
+
+// Two or more GPUs in one process: one thread per device, each with its own rank of one RCCL communicator and its
+// contiguous shard of the map; every rank must end up with the result of the single-GPU search.  Prints
+// "multi_gpu=skipped_one_gpu" on a machine with one GPU.
+static int multi_gpu_search(const std::vector<uint8_t>& q, int nq, const std::vector<uint8_t>& t, int64_t nt,
+                            const std::vector<orbx_match2>& want) {
+    int nd = 0;
+    HIPCHECK(hipGetDeviceCount(&nd));
+    if (nd < 2) { std::printf("multi_gpu=skipped_one_gpu\n"); return 0; }
+    uint8_t id[128];
+    CHECK(orbx_rccl_unique_id(id));
+    struct Rank {
+        void* comm = nullptr;
+        uint8_t *dq = nullptr, *dt = nullptr;
+        orbx_match2* dout = nullptr;
+        void* ws = nullptr;
+        size_t wsBytes = 0;
+        hipStream_t st = nullptr;
+        int64_t base = 0, nLocal = 0;
+        bool ready = false;
+    };
+    std::vector<Rank> R((size_t)nd);
+    std::vector<std::string> verdict((size_t)nd, "not run");
+    // Step 1, every rank: device buffers, its shard, its communicator rank.  The collective of step 2 only starts when
+    // all ranks got this far (a rank that stayed out of an all-gather would leave the others waiting for ever).
+    auto set_up = [&](int rank) {
+        Rank& k = R[rank];
+        if (hipSetDevice(rank) != hipSuccess) { verdict[rank] = "hipSetDevice failed"; return; }
+        const int64_t shard = nt / nd;               // equal contiguous shards, the last rank takes the remainder
+        k.base = rank * shard;
+        k.nLocal = rank < nd - 1 ? shard : nt - k.base;
+        k.wsBytes = orbx_knn2_sharded_workspace_bytes(nq, k.nLocal, nd);
+        const bool ok =
+            hipMalloc((void**)&k.dq, q.size()) == hipSuccess && hipMalloc((void**)&k.dt, (size_t)k.nLocal * 32 + 32) == hipSuccess &&
+            hipMalloc((void**)&k.dout, (size_t)nq * sizeof(orbx_match2)) == hipSuccess && hipMalloc(&k.ws, k.wsBytes) == hipSuccess &&
+            hipStreamCreateWithFlags(&k.st, hipStreamNonBlocking) == hipSuccess &&
+            hipMemcpyAsync(k.dq, q.data(), q.size(), hipMemcpyHostToDevice, k.st) == hipSuccess &&
+            hipMemcpyAsync(k.dt, t.data() + (size_t)k.base * 32, (size_t)k.nLocal * 32, hipMemcpyHostToDevice, k.st) == hipSuccess &&
+            hipStreamSynchronize(k.st) == hipSuccess;
+        if (!ok) { verdict[rank] = "device set-up failed"; return; }
+        if (orbx_rccl_comm_create(id, rank, nd, &k.comm) != ORBX_OK) { verdict[rank] = std::string("comm_create: ") + orbx_last_error(); return; }
+        k.ready = true;
+    };
+    auto search = [&](int rank) {
+        Rank& k = R[rank];
+        if (hipSetDevice(rank) != hipSuccess) { verdict[rank] = "hipSetDevice failed"; return; }
+        std::vector<orbx_match2> got((size_t)nq);
+        if (orbx_hamming_knn2_sharded_device(k.dq, nq, k.dt, k.nLocal, k.base, k.comm, k.dout, k.ws, k.wsBytes, k.st) != ORBX_OK)
+            verdict[rank] = std::string("sharded search: ") + orbx_last_error();
+        else if (hipMemcpyAsync(got.data(), k.dout, (size_t)nq * sizeof(orbx_match2), hipMemcpyDeviceToHost, k.st) != hipSuccess ||
+                 hipStreamSynchronize(k.st) != hipSuccess)
+            verdict[rank] = "download failed";
+        else
+            verdict[rank] = std::memcmp(got.data(), want.data(), (size_t)nq * sizeof(orbx_match2)) == 0 ? "OK" : "MISMATCH";
+    };
+    auto run_all = [&](auto&& fn) {
+        std::vector<std::thread> threads;
+        for (int r = 0; r < nd; ++r) threads.emplace_back(fn, r);
+        for (std::thread& th : threads) th.join();
+    };
+    run_all(set_up);                                   // (ncclCommInitRank is itself a collective: all ranks call it together)
+    bool allReady = true;
+    for (const Rank& k : R) allReady = allReady && k.ready;
+    if (allReady) run_all(search);
+    for (int r = 0; r < nd; ++r) {
+        Rank& k = R[r];
+        (void)hipSetDevice(r);
+        if (k.comm) orbx_rccl_comm_destroy(k.comm);
+        (void)hipFree(k.dq); (void)hipFree(k.dt); (void)hipFree(k.dout); (void)hipFree(k.ws);
+        if (k.st) (void)hipStreamDestroy(k.st);
+    }
+    bool all = true;
+    for (int r = 0; r < nd; ++r) {
+        if (verdict[r] != "OK") { all = false; std::printf("multi_gpu_rank%d=%s\n", r, verdict[r].c_str()); }
+    }
+    std::printf("multi_gpu=%s ranks=%d\n", all ? "OK" : "MISMATCH", nd);
+    HIPCHECK(hipSetDevice(0));
+    return 0;
 }
 
 int main() {
@@ -92,6 +174,7 @@ int main() {
     std::printf("sharded_short_workspace=%s\n",
                 orbx_hamming_knn2_sharded_device(dq, nq, dt, nt, 0, comm, dout, ws, 1024, st) == ORBX_ERR_INVALID ? "refused" : "accepted");
     orbx_rccl_comm_destroy(comm);
+    if (multi_gpu_search(q, nq, t, nt, want) != 0) return 1;
 
     // ---- extractor pool ----
     const int W = 640, H = 400, nFrames = 5;
