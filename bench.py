@@ -49,7 +49,6 @@ MBF, FX = 47.90639384423901, 435.2046959714599          # EuRoC-like baseline * 
 HBM_PEAK_GBS = 8000.0                                     # MI355X HBM3E spec
 VALU_U32_PEAK = 256 * 4 * 32 * 2.4e9                      # lane-ops/s (256 CU x 4 SIMD x 32 lanes x 2.4 GHz), nominal
 VALU_XOR_BCNT_MEASURED = 49.4e12                          # lane-ops/s of the search's own instruction pair, measured
-VALU_INT_MEASURED = 37.6e12                               # lane-ops/s of any single integer / byte VALU instruction, measured
 NQ_MAP, NT_MAP = 5000, 10_000_000
 
 
@@ -433,7 +432,7 @@ def main():
     # WRITE_SIZE passes whose summary is committed under profiles/ (FETCH_SIZE doubled: gfx950 tallies 128-byte
     # reads as 64 bytes); the JSON names that file as the source
     traffic, traffic_src = None, None
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")) as f:
                 t = json.load(f)
@@ -442,23 +441,38 @@ def main():
             break
         except (OSError, KeyError, ValueError):
             pass
-    # VALU work of a frame, from the committed counter pass (SQ_INSTS_VALU per kernel and launch of 64 frames), against
-    # the measured integer issue rate of the chip: the bound that actually limits the extraction
+    # Issue-bound ceiling of the extraction: every vector and scalar wave-instruction of a frame (committed counter pass:
+    # SQ_INSTS_VALU / SQ_INSTS_SALU per kernel and launch of 64 frames) charged its measured issue cost on the SIMD that
+    # issues it (profiles/<tag>_issue_model.json: per-kernel mean cost of a vector instruction from the kernel's
+    # instruction mix x the measured cost of each class; marginal cost of a scalar instruction), all 1024 SIMDs busy all
+    # the time.  Memory instructions, waits and barriers are not charged: a ceiling, not a prediction.
     valu = None
-    try:
-        import csv
-        with open(os.path.join(ROOT, "profiles", "r02_extract_euroc_b64_pmc_sq.csv")) as f:
-            rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
-        per_launch = {r["kernel"]: float(r["SQ_INSTS_VALU"]) for r in rows}
-        launches = {k: (NLEVELS - 1 if k == "k_resize" else 1) for k in per_launch}
-        wave_instr = sum(per_launch[k] * launches[k] for k in per_launch) / 64.0
-        ceiling = VALU_INT_MEASURED / (wave_instr * 64.0)
-        valu = {"wave_instructions_per_frame": wave_instr, "per_kernel_per_64_frames": per_launch,
-                "issue_rate_lane_ops_per_s": VALU_INT_MEASURED, "ceiling_frames_per_s": ceiling,
-                "source": "committed profile profiles/r02_extract_euroc_b64_pmc_sq.csv (SQ_INSTS_VALU; not measured by this run) and "
-                          "profiles/r02_ubench_valu_issue.txt (issue rate)"}
-    except (OSError, KeyError, ValueError):
-        pass
+    for tag in ("r03", "r02"):
+        try:
+            import csv
+            with open(os.path.join(ROOT, "profiles", f"{tag}_extract_euroc_b64_pmc_sq.csv")) as f:
+                rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
+            with open(os.path.join(ROOT, "profiles", "r03_issue_model.json")) as f:
+                model = json.load(f)
+            per_kernel, total_ns = {}, 0.0
+            for r in rows:
+                k = r["kernel"]
+                launches = NLEVELS - 1 if k == "k_resize" else 1
+                nv, ns = float(r["SQ_INSTS_VALU"]) * launches, float(r["SQ_INSTS_SALU"]) * launches
+                cv = model["kernels"].get(k, {}).get("mean_valu_cost_ns", model["valu_cost_ns_default"])
+                ns_total = nv * cv + ns * model["salu_cost_ns"]
+                per_kernel[k] = {"valu": nv, "salu": ns, "mean_valu_cost_ns": cv,
+                                 "issue_us_per_64_frames": ns_total / model["simds"] / 1e3}
+                total_ns += ns_total
+            ceiling = 64.0 / (total_ns / model["simds"] * 1e-9)
+            valu = {"per_kernel_per_64_frames": per_kernel, "salu_cost_ns": model["salu_cost_ns"],
+                    "issue_us_per_64_frames": total_ns / model["simds"] / 1e3, "ceiling_frames_per_s": ceiling,
+                    "source": f"committed profiles profiles/{tag}_extract_euroc_b64_pmc_sq.csv (instruction counts; not measured by "
+                              "this run) and profiles/r03_issue_model.json (costs); extraction kernels only, the stereo matcher's "
+                              "kernels are not charged"}
+            break
+        except (OSError, KeyError, ValueError):
+            pass
     fast_s = stage_ms["fast"] * 1e-3
     achieved = fast_bytes / fast_s / 1e9 if fast_s > 0 else 0.0
     frame_bytes = W * H + px + 60 * n_kp                                   # input + pyramid + keypoints/descriptors
@@ -482,7 +496,7 @@ def main():
                      "in_situ_note": "span between events in the timed two-stream pass: includes waiting behind the "
                                      "other camera's kernels",
                      "dominant_stage": dominant,
-                     "limit": "VALU issue, not HBM: instruction counts in profiles/r02_extract_euroc_b64_pmc_sq.csv"},
+                     "limit": "instruction issue, not HBM: see issue_bound"},
         "path_roofline": {"bound": "hbm", "bytes_per_frame": frame_bytes, "achieved": path_achieved, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": path_achieved / HBM_PEAK_GBS},
         "stage_ms_per_launch": stage_ms,
@@ -502,7 +516,7 @@ def main():
 
     if valu is not None:
         valu["frac_of_ceiling"] = value / world / valu["ceiling_frames_per_s"]
-        out["valu_issue"] = valu
+        out["issue_bound"] = valu
     if host_path is not None:
         out["host_path"] = host_path
     # release the EuRoC buffers before the larger legs

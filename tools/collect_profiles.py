@@ -45,16 +45,18 @@ def main(tag):
     os.makedirs(P, exist_ok=True)
     shutil.copy(os.path.join(G, f"{tag}_bench.json"), os.path.join(P, f"{tag}_bench.json"))
     bench = json.load(open(os.path.join(G, f"{tag}_bench.json")))
-    frames = bench["config"]["pairs_per_step_per_gpu"]
+    cfg = bench["config"]
+    frames = cfg["pairs_per_batch_per_gpu"] if "pairs_per_batch_per_gpu" in cfg else cfg["pairs_per_step_per_gpu"]
     stats(os.path.join(G, f"{tag}_prof", f"{tag}_kernel_stats.csv"), os.path.join(P, f"{tag}_bench_kernel_stats.csv"),
-          f"rocprofv3 --kernel-trace --stats -- python3 bench.py   (default: {frames} stereo pairs per step, "
-          f"{bench['steps']} steps + {bench['warmup']} warm-up, twice: plain pass + event-timed pass; 5+1 kNN searches 5000 x 10M)")
+          f"rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-pairs 0 --no-host-path   ({frames} stereo pairs per batch, "
+          f"{cfg.get('batches_per_step', 1)} batches per step, {bench['steps']} steps + {bench['warmup']} warm-up, plus the one-at-a-time, "
+          f"event-timed and roofline passes; 24+1 kNN searches 5000 x 10M)")
     # the launches of bench.py's roofline pass inside that trace: k_fast over the 752x480 batch with no other k_fast in flight
     tr = [r for r in csv.DictReader(open(os.path.join(G, f"{tag}_prof", f"{tag}_kernel_trace.csv"))) if "k_fast" in r["Kernel_Name"]]
     iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Grid_Size_Y", r.get("Grid_Size", ""))) for r in tr)
     euroc = [e - b for b, e, g in iv if g == str(frames)]
-    k = bench["steps"]
-    # the pass is `steps` consecutive launches of the left extractor alone: the window of that length with the smallest mean
+    k = 2 * bench["steps"]
+    # the pass is 2 x `steps` consecutive launches of the left extractor alone: the window of that length with the smallest mean
     best = min(range(len(euroc) - k + 1), key=lambda i: sum(euroc[i:i + k]))
     win = euroc[best:best + k]
     with open(os.path.join(P, f"{tag}_bench_kernel_stats.csv"), "a") as f:

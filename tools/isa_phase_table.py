@@ -7,6 +7,7 @@ Counts are instructions in the listing (a loop body counts once), split by what 
 vector memory, LDS, scalar memory, and the scalar side by kind -- waits, no-ops, branches, exec-mask bookkeeping,
 compares / selects, and plain scalar arithmetic (address and index arithmetic for the most part)."""
 import collections
+import json
 import re
 import sys
 
@@ -28,11 +29,39 @@ def kind(m):
     return "other"
 
 
+# Measured issue cost of vector instructions, ns per wave-instruction and SIMD with 8 waves per SIMD (tools/ubench/valu_rates.hip,
+# profiles/r02_ubench_valu_classes.txt, profiles/r03_ubench_f64_rates.txt): the plain 32-bit moves / logic / adds / float add and
+# multiply issue every other cycle, nearly everything else every fourth.
+VALU_COST_NS = {"v_mov_b32": 0.93, "v_and_b32": 0.95, "v_or_b32": 0.94, "v_xor_b32": 0.87, "v_not_b32": 0.92, "v_add_u32": 0.87,
+                "v_sub_u32": 0.86, "v_subrev_u32": 0.86, "v_lshrrev_b32": 0.88, "v_add_f32": 0.95, "v_mul_f32": 0.97, "v_sub_f32": 0.95,
+                "v_fma_f32": 1.21, "v_fmac_f32": 1.21, "v_bitop3_b32": 1.16, "v_rcp_f32": 3.47, "v_rcp_iflag_f32": 3.47}
+VALU_COST_DEFAULT_NS = 1.78
+
+
+def valu_cost(m):
+    m = re.sub(r"_(e32|e64|dpp|sdwa)$", "", m)
+    return VALU_COST_NS.get(m, VALU_COST_DEFAULT_NS)
+
+
 COLS = ["valu", "vmem", "lds", "smem", "s_waitcnt", "s_nop", "branch/barrier", "exec/mask", "cmp/select", "scalar alu"]
+
+
+def whole_kernel_mix(text):
+    """Per kernel of the listing: vector instructions and their mean issue cost by the table above (static mix)."""
+    out = {}
+    for m in re.finditer(r"^(_Z\w+):.*?\n(.*?)\.Lfunc_end", text, re.S | re.M):
+        costs = [valu_cost(l.strip().split()[0]) for l in m.group(2).split("\n")
+                 if l.startswith("\tv_")]
+        if costs:
+            out[m.group(1)] = {"valu_in_listing": len(costs), "mean_valu_cost_ns": sum(costs) / len(costs)}
+    return out
 
 
 def main(path):
     text = open(path).read()
+    if len(sys.argv) > 2 and sys.argv[2] == "--json":
+        print(json.dumps(whole_kernel_mix(text), indent=1))
+        return
     for name, (sym, phases) in KERNELS.items():
         m = re.search(r"^(_Z\w*%s\w*):.*?\n(.*?)\.Lfunc_end" % sym, text, re.S | re.M)
         if not m:
