@@ -104,8 +104,8 @@ class ORBextractor:
     def extract_batch(self, images, vLappingArea=(0, 0), copy=True):
         """One pass of every kernel over a list of equally sized host images (orbx_extract_batch: a batch of three
         upload chunks or more is pipelined -- staging, upload, kernels and download overlap).
-        Returns a list of (keypoints, descriptors, monoIndex); copy=False returns views into two arrays that the
-        extractor keeps and overwrites in its next batch call, instead of per-frame copies."""
+        Returns a list of (keypoints, descriptors, monoIndex), views into two arrays that hold the whole batch;
+        copy=False returns views into the arrays that the extractor keeps and overwrites in its next batch call."""
         nf = len(images)
         assert 1 <= nf <= self.max_batch
         h, w = images[0].shape
@@ -122,16 +122,16 @@ class ORBextractor:
         mono = np.zeros(nf, np.int32)
         while True:
             cap = self.max_keypoints
-            # copy=False: the two result arrays belong to the extractor and are reused by the next call of the same
-            # shape, as a C++ caller reuses its vectors (fresh arrays cost a page fault per 4 KB the library writes)
+            # The library writes into two arrays that belong to the extractor and are reused by the next call of the
+            # same shape, as a C++ caller reuses its vectors (fresh arrays cost a page fault per 4 KB the library
+            # writes); copy=True then copies each frame's used rows out of them.
             held = getattr(self, "_batch_out", None)
-            if not copy and held is not None and held[0].shape == (nf, cap):
+            if held is not None and held[0].shape == (nf, cap):
                 kps, desc = held
             else:
                 kps = np.empty((nf, cap), KP_DTYPE)
                 desc = np.empty((nf, cap, 32), np.uint8)
-                if not copy:
-                    self._batch_out = (kps, desc)
+                self._batch_out = (kps, desc)
             try:
                 check(self._L.orbx_extract_batch(self._h, ptrs, nf, w, h, stride, int(vLappingArea[0]), int(vLappingArea[1]),
                                                  ptr(kps), ptr(desc), cap, ptr(n), ptr(mono)))
@@ -139,9 +139,12 @@ class ORBextractor:
             except OrbxError:
                 if not self._capacity_grew():
                     raise
-        if not copy:
-            return [(kps[f, :n[f]], desc[f, :n[f]], int(mono[f])) for f in range(nf)]
-        return [(kps[f, :n[f]].copy(), desc[f, :n[f]].copy(), int(mono[f])) for f in range(nf)]
+        if copy:
+            # one copy of the used part of both arrays (the per-frame results are views into it): two allocations per
+            # call instead of two per frame
+            nmax = int(n.max()) if nf else 0
+            kps, desc = kps[:, :nmax].copy(), desc[:, :nmax].copy()
+        return [(kps[f, :n[f]], desc[f, :n[f]], int(mono[f])) for f in range(nf)]
 
     def extract_batch_arrays(self, stack, vLappingArea=(0, 0)):
         """orbx_extract_batch on a stack of host images [n, H, W] (uint8, unit pixel stride; any row and frame
