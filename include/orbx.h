@@ -637,7 +637,7 @@ orbx_status orbx_distinctive_descriptors(const uint8_t* desc, const int* off, in
 /* Frame::ComputeStereoFishEyeMatches (Frame.cc:1286-1338), the whole member: brute-force k = 2 search of the
  * left descriptors [mono_left, n_left) in the right descriptors [mono_right, n_right) (Frame.cc:1290-1309), Lowe's
  * ratio test `best < 0.7 * second` in double as the reference evaluates it (:1318), KannalaBrandt8::TriangulateMatches
- * (KannalaBrandt8.cpp:336-401) of every match that passes with R_lr / t_lr = Frame::mRlr / mtlr (row-major 3x3, 3) and
+ * (KannalaBrandt8.cpp:323-397) of every match that passes with R_lr / t_lr = Frame::mRlr / mtlr (row-major 3x3, 3) and
  * sigma = level_sigma2[octave] of the two keypoints, accepted when the depth exceeds 0.0001 (:1328).  Matches are
  * visited in ascending left index, so a right keypoint claimed twice keeps the later left one, as in the
  * reference.  Outputs (host): left_to_right[n_left] / right_to_left[n_right] = mvLeftToRightMatch /
