@@ -4,6 +4,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -60,6 +62,9 @@ extern "C" orbx_status orbx_hamming_knn2_sharded_device(const uint8_t* d_query, 
     // all-gather, and the other ranks wait in it -- as after any failed rank of a collective, the caller has to tear
     // the communicator down (ncclCommAbort / orbx_rccl_comm_destroy) on all ranks.
     DIST_REQUIRE(n_train_shard == 0 || d_train_shard, "null shard of %lld rows", (long long)n_train_shard);
+    DIST_REQUIRE(base_index + n_train_shard <= (int64_t)INT_MAX, "train index does not fit 32 bits");
+    DIST_REQUIRE((((uintptr_t)d_query | (uintptr_t)d_train_shard | (uintptr_t)d_workspace) & 15) == 0,
+                 "descriptor arrays and workspace must be 16-byte aligned");
     orbx_status s = orbx_hamming_knn2_device(d_query, n_query, d_train_shard, n_train_shard, base_index, local, inner,
                                              workspace_bytes - (size_t)(inner - ws), stream);
     if (s != ORBX_OK) return s;
