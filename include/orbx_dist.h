@@ -26,9 +26,9 @@ extern "C" {
  * lower global index).  A shard may be empty.  `d_workspace` holds orbx_knn2_sharded_workspace_bytes().
  * Does not synchronise; as with any collective, all ranks of the communicator must make the call.  Every check that
  * depends on the arguments (null pointers, alignment, the 32-bit index range of this rank's shard, the workspace size)
- * is made before anything is enqueued, so a rank that returns ORBX_ERR_INVALID has not started the collective; a rank
- * that fails later (ORBX_ERR_HIP) has left the others waiting in the all-gather, and the caller must abort the
- * communicator on all ranks.  Verified with one rank on real RCCL and with 2 and 3 ranks over gloo through the
+ * is made before anything is enqueued, so a rank that returns ORBX_ERR_INVALID has enqueued nothing; whenever any
+ * rank returns a status other than ORBX_OK it has not entered the all-gather, the other ranks wait in it, and the
+ * caller must abort the communicator on all ranks.  Verified with one rank on real RCCL and with 2 and 3 ranks over gloo through the
  * torch.distributed binding of the same protocol; not yet run with more than one RCCL rank. */
 size_t orbx_knn2_sharded_workspace_bytes(int n_query, int64_t n_train_shard, int world_size);
 orbx_status orbx_hamming_knn2_sharded_device(const uint8_t* d_query, int n_query, const uint8_t* d_train_shard,
