@@ -1488,9 +1488,8 @@ __device__ __forceinline__ constexpr uint32_t hblur_weight(int byteOffset, int d
 // vertical pass keeps, per pixel column, the last six sums as packed pairs of consecutive rows in registers (the row
 // loop is unrolled six times so that the ring needs no moves): three v_dot2_u32_u16 and one multiply-add per output.
 // The first and last lane of a band are halo lanes (they load and take part in the exchange, and store nothing).
-// REFLECT_101 at the level's own edge: rows by reflecting the row index, columns by a per-lane byte selector -- a
-// lane whose pixels lie beyond the edge loads the one or two dwords that hold their mirror images and one
-// v_perm_b32 puts them in place (the selector is the identity for every other lane).
+// REFLECT_101 at the level's own edge: rows by reflecting the row index, columns by byte permutes in the two edge
+// lanes (see the kernel).
 // ======================================================================================
 constexpr int kBlurTileCols = 62;       // dword columns of a full-width tile
 struct alignas(16) OrbxBlurTile {
@@ -1507,11 +1506,15 @@ __device__ __forceinline__ uint32_t dpp_from_upper_lane(uint32_t v) {   // lane 
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 }
 
-__global__ __launch_bounds__(256) void k_blur_levels(const OrbxBlurTile* __restrict__ tiles, int nTiles, int stripRows,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_blur_levels(const OrbxBlurTile* __restrict__ tiles, int nTiles, int stripRows,
                                                      const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blurred,
                                                      long long frameStride) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + wave;
+    // Neighbouring tiles share cache lines (a tile's 256-byte row segments start at multiples of 248 bytes) and halo
+    // rows: keep them on one XCD, close in time, so that the shared lines come from that XCD's L2 (see xcd_remap).
+    const int logical = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int frame = logical / (int)gridDim.x;
+    const int t = (logical - frame * (int)gridDim.x) * 4 + wave;
     if (t >= nTiles) return;
     const OrbxBlurTile T = tiles[t];
     const int w = T.wh & 0xFFFF, h = T.wh >> 16, pitch = T.pitchShape & 0xFFFF;
@@ -1523,24 +1526,30 @@ __global__ __launch_bounds__(256) void k_blur_levels(const OrbxBlurTile* __restr
     const int c = col0 + pos - 1;                           // this lane's dword column (-1: left of the level)
     const int yBand = y0 + band * stripRows;
     const int lastCol = (w - 1) >> 2;
-    const uint8_t* __restrict__ src = pyr + (long long)blockIdx.y * frameStride + T.imgOff;
-    uint8_t* __restrict__ dst = blurred + (long long)blockIdx.y * frameStride + T.imgOff;
+    const uint8_t* __restrict__ src = pyr + (long long)frame * frameStride + T.imgOff;
+    uint8_t* __restrict__ dst = blurred + (long long)frame * frameStride + T.imgOff;
 
-    // where the lane's four pixels come from: pixel p of the level, or its mirror image
-    int q[4];
+    // REFLECT_101 at the level's left and right edge.  Every lane loads the dword of its own column (clamped into the
+    // level).  The pixels beyond an edge are mirror images of pixels that the edge lane and its inner neighbour hold,
+    // so the two edge lanes build them with byte permutes instead of receiving them from a halo lane:
+    //   first column (c = 0):     L' = pixels -4..-1 = (4, 3, 2, 1) = (R.0, C.3, C.2, C.1)
+    //   last column, m = (w - 1) & 3 the byte of the level's last pixel: C' byte b > m = pixel w - 1 - (b - m), and
+    //   R' byte b <= m - 1 (the only ones a stored pixel's window reaches) = pixel w - 1 - (4 + b - m): bytes of C, or
+    //   of L when the offset is negative -- v_perm_b32(C, L, selector 4 + offset) serves both.
+    // Tiles without an edge column skip all of it (a wave-uniform test).
+    const int m = (w - 1) & 3;
+    const bool isFirst = c == 0, isLast = c == lastCol;
+    const bool edgeTile = col0 == 0 || col0 + cw - 1 >= lastCol;                          // wave-uniform
+    uint32_t selC = 0x07060504u, selR = 0x0c0c0c0cu;
+    if (isLast) {
+        selC = 0; selR = 0;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        int p = 4 * c + b;
-        if (p < 0) p = -p;
-        if (p >= w) p = 2 * (w - 1) - p;
-        q[b] = min(max(p, 0), w - 1);                       // (lanes far outside the level: anything in range)
+        for (int bb = 0; bb < 4; ++bb) {
+            selC |= (uint32_t)(bb <= m ? 4 + bb : 4 + 2 * m - bb) << (8 * bb);
+            selR |= (uint32_t)(bb <= m - 1 ? 2 * m - bb : 0x0c) << (8 * bb);
+        }
     }
-    const int qmin = min(min(q[0], q[1]), min(q[2], q[3])), qmax = max(max(q[0], q[1]), max(q[2], q[3]));
-    const int colA = qmin >> 2, colB = min(colA + 1, lastCol);
-    uint32_t sel = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) sel |= (uint32_t)((q[b] - 4 * colA) & 7) << (8 * b);    // 0..3: first dword, 4..7: second
-    const bool twoLoads = __builtin_amdgcn_readfirstlane((int)(__ballot((qmax >> 2) != colA) != 0ull)) != 0;
+    const int cl = min(max(c, 0), lastCol);
     const bool stores = bandRaw < nb && pos >= 1 && pos <= cw && c <= lastCol;
 
     uint32_t P[4][6];            // P[k][j % 6] = H_k(row j) | H_k(row j + 1) << 16, H_k = row sum of the lane's k-th pixel
@@ -1554,7 +1563,7 @@ __global__ __launch_bounds__(256) void k_blur_levels(const OrbxBlurTile* __restr
     // Byte offset of source row r of the lane's band (mirrored at the level's top and bottom).  Only the trips that
     // touch the top or the bottom of the level (a wave-uniform test over all bands of the tile) pay for the mirror;
     // the others add a scalar to the lane's first row.
-    const uint32_t plainA = (uint32_t)((yBand - 3) * pitch + 4 * colA), plainB = (uint32_t)((yBand - 3) * pitch + 4 * colB);
+    const uint32_t plainIn = (uint32_t)((yBand - 3) * pitch + 4 * cl);
     const uint32_t plainOut = (uint32_t)(yBand * pitch + 4 * c);
     const int lastBandY = y0 + (nb - 1) * stripRows;
     auto mirrored_row = [&](int r) {
@@ -1565,34 +1574,37 @@ __global__ __launch_bounds__(256) void k_blur_levels(const OrbxBlurTile* __restr
     };
     // The six rows of a trip are loaded one trip ahead of their use: a wave waits for memory once per trip, with a
     // trip's arithmetic in between, instead of once per row.
-    uint32_t curA[6], curB[6], nxtA[6], nxtB[6];
-    auto load_trip = [&](int rBase, uint32_t (&A)[6], uint32_t (&B)[6]) {
+    uint32_t cur[6], nxt[6];
+    auto load_trip = [&](int rBase, uint32_t (&A)[6]) {
         const bool edge = y0 - 3 + rBase < 0 || lastBandY - 3 + rBase + 5 >= h;          // wave-uniform
         if (edge) {
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const uint32_t ro = mirrored_row(rBase + u);
-                A[u] = *reinterpret_cast<const uint32_t*>(src + (ro + 4u * (uint32_t)colA));
-                B[u] = twoLoads ? *reinterpret_cast<const uint32_t*>(src + (ro + 4u * (uint32_t)colB)) : 0u;
-            }
+            for (int u = 0; u < 6; ++u)
+                A[u] = *reinterpret_cast<const uint32_t*>(src + (mirrored_row(rBase + u) + 4u * (uint32_t)cl));
         } else {
 #pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const uint32_t so = (uint32_t)((rBase + u) * pitch);                       // scalar
-                A[u] = *reinterpret_cast<const uint32_t*>(src + (plainA + so));
-                B[u] = twoLoads ? *reinterpret_cast<const uint32_t*>(src + (plainB + so)) : 0u;
-            }
+            for (int u = 0; u < 6; ++u)
+                A[u] = *reinterpret_cast<const uint32_t*>(src + (plainIn + (uint32_t)((rBase + u) * pitch)));
         }
     };
-    load_trip(0, curA, curB);
+    load_trip(0, cur);
     const int trips = stripRows / 6 + 1;                    // stripRows + 6 source rows (stripRows is a multiple of 6)
     for (int r6 = 0; r6 < trips; ++r6) {
-        load_trip(6 * (r6 + 1), nxtA, nxtB);                // (one trip past the end: mirrored or clamped rows, unused)
+        if (r6 + 1 < trips) load_trip(6 * (r6 + 1), nxt);
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
             const int r = 6 * r6 + u;
-            const uint32_t C = __builtin_amdgcn_perm(curB[u], curA[u], sel);   // (the identity wherever one load suffices)
-            const uint32_t L = dpp_from_lower_lane(C), R = dpp_from_upper_lane(C);
+            uint32_t C = cur[u], L, R;
+            if (edgeTile) {
+                const uint32_t Ld = dpp_from_lower_lane(C);
+                C = __builtin_amdgcn_perm(C, Ld, selC);                     // (the identity except in the last column)
+                const uint32_t Rd = dpp_from_upper_lane(C);
+                R = isLast ? __builtin_amdgcn_perm(C, Ld, selR) : Rd;
+                L = isFirst ? __builtin_amdgcn_perm(Rd, C, 0x01020304u) : Ld;
+            } else {
+                L = dpp_from_lower_lane(C);
+                R = dpp_from_upper_lane(C);
+            }
             // horizontal sums of the lane's 4 pixels: the window of pixel k starts at byte k + 1 of (L, C, R)
             uint32_t H[4];
             H[0] = __builtin_amdgcn_udot4(C, hblur_weight(1, 1), __builtin_amdgcn_udot4(L, hblur_weight(1, 0), 0u, false), false);
@@ -1618,7 +1630,7 @@ __global__ __launch_bounds__(256) void k_blur_levels(const OrbxBlurTile* __restr
             for (int k = 0; k < 4; ++k) Hprev[k] = H[k];
         }
 #pragma unroll
-        for (int u = 0; u < 6; ++u) { curA[u] = nxtA[u]; curB[u] = nxtB[u]; }
+        for (int u = 0; u < 6; ++u) cur[u] = nxt[u];
     }
 }
 
