@@ -526,26 +526,31 @@ def main():
     # --- 1920x1080 / 5000 features, batched extraction of distinct synthetic frames (1024 frames per measurement)
     if not args.no_1080p:
         HW, HH, HN, HB = 1920, 1080, 5000, args.batch_1080p
-        # two handles on two streams, as for the stereo leg: 2 x HB distinct frames resident in HBM
+        # NH handles on NH streams (as the stereo leg's two sets of two): 2 x HB distinct frames resident in HBM
+        NH = max(2, int(os.environ.get("ORBX_BENCH_1080P_HANDLES", "2")))
         frames = np.stack([synth.scene(HW, HH, 500000 * (rank + 1) + i, n_prims=1500) for i in range(2 * HB)])
         dF = [torch.from_numpy(frames[:HB]).to(dev), torch.from_numpy(frames[HB:]).to(dev)]
+        dF = [dF[k % 2] for k in range(NH)]
         del frames
-        exs = [A.ORBextractor(HN, SCALE, NLEVELS, INI_TH, MIN_TH, HW, HH, max_batch=HB, device=local) for _ in range(2)]
+        exs = [A.ORBextractor(HN, SCALE, NLEVELS, INI_TH, MIN_TH, HW, HH, max_batch=HB, device=local) for _ in range(NH)]
         exH = exs[0]
         capH = exH.max_keypoints
         mkH = lambda: (torch.empty((HB, capH, 28), dtype=torch.uint8, device=dev),
                        torch.empty((HB, capH, 32), dtype=torch.uint8, device=dev),
                        torch.empty((HB, 2), dtype=torch.int32, device=dev))
-        outs = [mkH(), mkH()]
+        outs = [mkH() for _ in range(NH)]
         outH = outs[0]
         sA = torch.cuda.Stream(dev)
         sB, overlapH = pick_concurrent_stream(torch, dev, [sA])
         streams = [sA, sB]
+        for _ in range(2, NH):
+            streams.append(pick_concurrent_stream(torch, dev, streams)[0])
         for _ in range(2):
-            for k in range(2):
+            for k in range(NH):
                 exs[k].extract_batch_device(dF[k], (0, 0), out=outs[k])
             torch.cuda.synchronize()
-            exs[0].status(); exs[1].status()
+            for e in exs:
+                e.status()
         # 27 x 1024 frames per two-stream measurement: more than half a second of GPU work
         launches = max(2, (27 * 1024 // HB) & ~1)
 
@@ -553,12 +558,13 @@ def main():
             barrier(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(launches):
-                k = i % 2
+                k = i % (NH if n_streams > 1 else 2)
                 with torch.cuda.stream(streams[k % n_streams]):
                     exs[k].extract_batch_device(dF[k], (0, 0), out=outs[k])
             torch.cuda.synchronize(); barrier()
             d = time.perf_counter() - t0
-            exs[0].status(); exs[1].status()
+            for e in exs:
+                e.status()
             if world > 1:
                 t = torch.tensor([d], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -566,7 +572,7 @@ def main():
             return d
         launches1 = max(2, (launches // 4) & ~1)
         dth1 = run(1, launches1)
-        dth = run(2, launches)
+        dth = run(NH, launches)
         exH.set_timing(True)
         for _ in range(4):
             with torch.cuda.stream(sA):
@@ -580,7 +586,7 @@ def main():
         fpsH = launches * HB * world / dth
         out["extract_1080p"] = {
             "workload": f"synthetic 1920x1080, nFeatures=5000, 8 levels x1.2, FAST 20/7: {launches} launches of {HB} frames per GPU "
-                        f"({2 * HB} distinct frames), two extractor handles alternating on two streams, inputs resident in HBM",
+                        f"({2 * HB} distinct frames), {NH} extractor handles alternating on {NH} streams, inputs resident in HBM",
             "frames_per_s": fpsH, "ms_per_frame": 1e3 * dth / (launches * HB), "keypoints_per_frame": nkH,
             "one_stream_frames_per_s": launches1 * HB * world / dth1,
             "timed_region_s": dth,

@@ -201,6 +201,11 @@ orbx_status orbx_extractor_get_timing(orbx_extractor* ex, double* stage_ms, int 
  * cell-by-cell emission order); returns the count through *n_out. */
 orbx_status orbx_debug_level_candidates(orbx_extractor* ex, int frame, int level, float* xyr, uint32_t* order_key,
                                         int capacity, int* n_out);
+/* cv::GaussianBlur(mvImagePyramid[level], 7x7, sigma 2, BORDER_REFLECT_101) (ORBextractor.cc:1344-1351) as the last call
+ * left it in frame slot `frame`: width * height bytes, rows packed.  Only a handle whose keypoint quota is dense enough
+ * that it blurs whole levels keeps such an image (ORBX_BLUR_MODE=level forces that); ORBX_ERR_INVALID otherwise. */
+orbx_status orbx_debug_blurred_level(orbx_extractor* ex, int frame, int level, uint8_t* out, size_t capacity,
+                                     int* width, int* height);
 /* Keypoints of one level after quadtree distribution, in node-list order, level coordinates. */
 orbx_status orbx_debug_level_keypoints(orbx_extractor* ex, int frame, int level, float* xyr, int capacity,
                                        int* n_out);

@@ -57,6 +57,8 @@ PROTOTYPES = {
                                      C.POINTER(C.c_int)]),
     "orbx_pyramid_level_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int),
                                             C.POINTER(C.c_int), C.POINTER(C.c_ssize_t)]),
+    "orbx_debug_blurred_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int),
+                                           C.POINTER(C.c_int)]),
     "orbx_debug_level_candidates": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                               C.POINTER(C.c_int)]),
     "orbx_search_window_best": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1539,7 +1539,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // Tiles without an edge column skip all of it (a wave-uniform test).
     const int m = (w - 1) & 3;
     const bool isFirst = c == 0, isLast = c == lastCol;
-    const bool edgeTile = col0 == 0 || col0 + cw - 1 >= lastCol;                          // wave-uniform
+    // (wave-uniform; "+ cw", not "+ cw - 1": when the last column is a tile's right halo lane its bytes beyond the level's
+    // width still feed the windows of the lane before it, and must be mirrored too)
+    const bool edgeTile = col0 == 0 || col0 + cw >= lastCol;
     uint32_t selC = 0x07060504u, selR = 0x0c0c0c0cu;
     if (isLast) {
         selC = 0; selR = 0;
@@ -2984,6 +2986,24 @@ extern "C" orbx_status orbx_pyramid_level(orbx_extractor* ex, int frame, int lev
     ORBX_HIP_TRY(hipSetDevice(ex->device));
     ORBX_HIP_TRY(hipStreamSynchronize(ex->stream));
     ORBX_HIP_TRY(hipMemcpy2D(out, w, d, pitch, w, h, hipMemcpyDeviceToHost));
+    return ORBX_OK;
+}
+
+// Diagnostics: the blurred level `level` of frame slot `frame` as the last call left it (handles that blur whole levels
+// only: ORBX_ERR_INVALID for one that blurs per keypoint patch).  out: width * height bytes, rows packed.
+extern "C" orbx_status orbx_debug_blurred_level(orbx_extractor* ex, int frame, int level, uint8_t* out, size_t capacity,
+                                                int* width, int* height) {
+    ORBX_REQUIRE(ex && ex->geoValid, "no geometry yet");
+    ORBX_REQUIRE(ex->levelBlur && ex->d_blur, "this handle blurs per keypoint patch: there is no blurred level");
+    ORBX_REQUIRE(frame >= 0 && frame < ex->prm.max_batch && level >= 0 && level < ex->geo.nlevels, "bad frame / level");
+    const OrbxLevelGeo& L = ex->geo.lv[level];
+    if (width) *width = L.w;
+    if (height) *height = L.h;
+    if (!out) return ORBX_OK;
+    if (capacity < (size_t)L.w * L.h) { orbx_set_error("buffer too small for a %dx%d level", L.w, L.h); return ORBX_ERR_CAPACITY; }
+    ORBX_HIP_TRY(hipSetDevice(ex->device));
+    ORBX_HIP_TRY(hipStreamSynchronize(ex->stream));
+    ORBX_HIP_TRY(hipMemcpy2D(out, L.w, ex->d_blur + (size_t)frame * ex->geo.pyrBytes + L.off, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
     return ORBX_OK;
 }
 

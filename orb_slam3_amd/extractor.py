@@ -252,6 +252,15 @@ class ORBextractor:
         check(self._L.orbx_pyramid_level(self._h, frame, level, ptr(out), out.size, C.byref(w), C.byref(h)))
         return out
 
+    def debug_blurred_level(self, level: int, frame: int = 0) -> np.ndarray:
+        """GaussianBlur(mvImagePyramid[level]) of the last call, for an extractor that blurs whole levels (raises
+        otherwise)."""
+        w, h = C.c_int(), C.c_int()
+        check(self._L.orbx_debug_blurred_level(self._h, frame, level, None, 0, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        check(self._L.orbx_debug_blurred_level(self._h, frame, level, ptr(out), out.size, C.byref(w), C.byref(h)))
+        return out
+
     def debug_level_candidates(self, level: int, frame: int = 0):
         cap = 1 << 22
         xyr = np.zeros((cap, 3), np.float32)

@@ -128,6 +128,44 @@ def test_scale_factor_and_levels_variants(oracle):
         _same(*o(img, (0, 0)), *g(img, (0, 0)))
 
 
+def test_blurred_levels_equal_the_oracle_on_every_pixel(oracle, blur_mode):
+    """k_blur_levels against the oracle's GaussianBlur on EVERY pixel of every level (the descriptor tests only see the
+    pixels that some keypoint samples).  Widths are chosen for the kernel's edge cases: a level whose number of dword
+    columns is 1 more than a multiple of the 62 a tile stores (the last column is then a tile's halo lane), all four
+    values of the width modulo 4, levels narrower than one tile, fewer rows than one strip, and batches in frame slots
+    other than 0 whose row padding holds other data."""
+    if blur_mode != "level":
+        pytest.skip("per-patch mode keeps no blurred level")
+    A = _gpu()
+    import torch
+    sizes = [(1241, 376, 1.0 + 1e-6), (249, 130, 1.2), (250, 171, 1.2), (251, 102, 1.1), (997, 333, 1.25), (1553, 420, 1.25),
+             (745, 480, 1.2), (497, 131, 1.5), (120, 110, 1.2)]
+    for case, (w, h, sf) in enumerate(sizes):
+        nl = 1 if sf < 1.001 else 4
+        sf = max(sf, 1.1)
+        while nl > 1 and min(w, h) / sf ** (nl - 1) < 40:
+            nl -= 1
+        imgs = np.stack([synth.scene(w, h, 700 + 3 * case + f, n_prims=150, noise_sigma=2.0) for f in range(3)])
+        # rows and frames padded with bytes that are not image data
+        buf = torch.full((3, h + 2, w + 37), 201, dtype=torch.uint8, device="cuda")
+        buf[:, :h, :w] = torch.from_numpy(imgs).cuda()
+        g = A.ORBextractor(800, sf, nl, 20, 7, max_width=w, max_height=h, max_batch=3)
+        g.extract_batch_device(buf[:, :h, :w], (0, 0))
+        torch.cuda.synchronize()
+        g.status()
+        for f in range(3):
+            o = oracle.Extractor(800, sf, nl, 20, 7)
+            o(imgs[f], (0, 0))
+            for l in range(nl):
+                want = oracle.gaussian7(o.pyramid_level(l))
+                got = g.debug_blurred_level(l, f)
+                if not np.array_equal(want, got):
+                    ys, xs = np.nonzero(want != got)
+                    raise AssertionError(f"{w}x{h} sf={sf} frame {f} level {l} ({want.shape[1]}x{want.shape[0]}): {len(ys)} pixels "
+                                         f"differ, first at x={xs[0]} y={ys[0]}, columns {sorted(set(xs.tolist()))[:8]}")
+        g.close()
+
+
 def test_random_geometries(oracle):
     # Sizes, pyramid shapes, quotas and thresholds drawn at random: the cell grid, the tile pitch, the rows a FAST
     # wave takes and the alignment of every level row all depend on them.

@@ -1,5 +1,5 @@
 #!/bin/bash
-# k_fast with n extra scalar moves per quick-reject row step (diagnostic builds build/liborbx_salu<n>.so, -DORBX_EXTRA_SALU=n):
+# k_fast with n extra scalar moves per quick-reject row step (diagnostic builds: make -C orb_slam3_amd/csrc extra-salu):
 # kernel time and scalar / vector instruction counts per launch of 64 EuRoC frames.   bash tools/extra_salu.sh
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
