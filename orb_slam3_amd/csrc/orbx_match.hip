@@ -358,6 +358,8 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restr
   // the next unclaimed span of this query group; the counter only grows, so the loop ends for every wave once it
   // has passed nSpans (the host clears the counters before the launch)
   for (;;) {
+    // (spans claimed per workgroup instead, so that its four waves read the same rows and share them in the scalar
+    // cache, with a barrier per span: 22.93 against 22.40 ms -- the scalar loads are not what the waves wait for)
     int span = 0;
     if (lane == 0) span = atomicAdd(&spanCounter[group], 1);
     span = __builtin_amdgcn_readfirstlane(span);
