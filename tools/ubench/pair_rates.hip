@@ -18,7 +18,11 @@
     X(3, "v_xor(sgpr) alone", "v_xor_b32 %0, %3, %0", 1)                                                              \
     X(4, "v_xor(vgpr) alone", "v_xor_b32 %0, %4, %0", 1)                                                              \
     X(5, "v_fma_f32 (control)", "v_fma_f32 %0, %4, %0, %0", 1)                                                        \
-    X(6, "v_add_u32(vgpr) (control)", "v_add_u32 %0, %4, %0", 1)
+    X(6, "v_add_u32(vgpr) (control)", "v_add_u32 %0, %4, %0", 1)                                                      \
+    X(7, "v_xor(16 sgprs in turn) + v_bcnt", "v_xor_b32 %1, %5, %2\n\tv_bcnt_u32_b32 %0, %1, %0", 2)                     \
+    X(8, "v_xor(16 sgprs in turn) alone", "v_xor_b32 %0, %5, %0", 1)                                                  \
+    X(9, "v_xor(sgprs) + v_bcnt, 4 chains", "v_xor_b32 %1, %5, %2\n\tv_bcnt_u32_b32 %0, %1, %0", 2)                   \
+    X(10, "the same, loop body of 1024 instructions", "v_xor_b32 %1, %5, %2\n\tv_bcnt_u32_b32 %0, %1, %0", 2)
 
 struct Stamp { unsigned long long c0, c1, r0, r1; };
 
@@ -30,13 +34,17 @@ __global__ __launch_bounds__(256) void k(unsigned* out, Stamp* stamps, int iters
 #pragma unroll
     for (int i = 0; i < 8; ++i) q[i] = acc[i] * 7u + 1u;
     const unsigned s = __builtin_amdgcn_readfirstlane(seed * 77u + 3u);
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
-    for (int it = 0; it < iters; ++it) {
+    unsigned sv[16];            // sixteen different scalar registers, as the search kernel's train rows are
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+    for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_readfirstlane(seed * (31u + i) + i); asm volatile("" : "+s"(sv[i])); }
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    constexpr int kReps = KIND == 10 ? 32 : 4;         // 16 groups each: 128 or 1024 instructions per trip for a pair row
+    for (int it = 0; it < iters * 4 / kReps; ++it) {
+#pragma unroll
+        for (int r = 0; r < kReps; ++r)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-#define X(id, name, text, n) if (KIND == id) asm volatile(text : "+v"(acc[i]), "=&v"(tmp) : "v"(q[i & 7]), "s"(s), "v"(v2));
+#define X(id, name, text, n) if (KIND == id) asm volatile(text : "+v"(acc[KIND >= 9 ? (i & 3) : i]), "=&v"(tmp) : "v"(q[i & 7]), "s"(s), "v"(v2), "s"(sv[i]));
                 KINDS(X)
 #undef X
             }
@@ -49,8 +57,9 @@ __global__ __launch_bounds__(256) void k(unsigned* out, Stamp* stamps, int iters
     if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * 4 + (threadIdx.x >> 6)] = Stamp{c0, c1, r0, r1};
 }
 
+static int g_long = 1;     // argv[1]: run every row this many times longer (does the clock hold under a long launch?)
 template <int KIND> void run(const char* name, int perIter, int cus, int W) {
-    const int blocks = cus * W, threads = 256, iters = 4000;
+    const int blocks = cus * W, threads = 256, iters = 4000 * g_long;
     unsigned* d; Stamp* ds;
     if (hipMalloc(&d, (size_t)blocks * threads * 4) != hipSuccess || hipMalloc(&ds, (size_t)blocks * 4 * sizeof(Stamp)) != hipSuccess) { printf("hipMalloc failed\n"); exit(1); }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -78,12 +87,13 @@ template <int KIND> void run(const char* name, int perIter, int cus, int W) {
     hipFree(d); hipFree(ds); hipEventDestroy(e0); hipEventDestroy(e1);
 }
 
-int main() {
+int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IOLBF, 0);
+    if (argc > 1) g_long = std::max(1, atoi(argv[1]));
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
     printf("%s, %d CUs; a group = the row's instruction(s) once per lane\n", p.name, cus);
-    for (int W : {1, 2, 4, 8}) {
+    for (int W : (g_long > 1 ? std::vector<int>{8} : std::vector<int>{1, 2, 4, 8})) {
 #define X(id, name, text, n) run<id>(name, n, cus, W);
         KINDS(X)
 #undef X
