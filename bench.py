@@ -670,9 +670,10 @@ def main():
                           "roofline": {"bound": "valu-u32", "ops_per_pair": 16, "achieved": pairs_s * 16 / 1e12,
                                        "peak": VALU_XOR_BCNT_MEASURED * world / 1e12, "unit": "Tops/s",
                                        "frac": pairs_s * 16 / (VALU_XOR_BCNT_MEASURED * world),
-                                       "peak_evidence": "profiles/r02_ubench_valu_issue.txt: the v_xor_b32 + "
-                                                        "v_bcnt_u32_b32 pair issues at 49.4 T lane-ops/s at 8 waves per "
-                                                        "SIMD (either instruction alone: 37.5 T; v_fma_f32: 56 T)",
+                                       "peak_evidence": "profiles/r03_ubench_pair_rates.txt: the v_xor_b32 + "
+                                                        "v_bcnt_u32_b32 pair issues at 49 T lane-ops/s (6.3 cycles per pair "
+                                                        "and SIMD) at 2, 4 and 8 waves per SIMD, all waves co-resident "
+                                                        "(either instruction alone: 37.5 T)",
                                        "nominal_peak": VALU_U32_PEAK * world / 1e12,
                                        "frac_of_nominal": pairs_s * 16 / (VALU_U32_PEAK * world)}}
 
