@@ -228,13 +228,18 @@ __global__ __launch_bounds__(kPyrThreadsMax) void k_resize(const OrbxFrameGeo* _
 // 16 bytes per lane when the source is 16-byte aligned, bytes otherwise.  The first workgroup of every frame also
 // clears the frame's FAST candidate counters (the only per-batch state that must start at zero), which saves a
 // separate memset on the stream.
+// The FAST candidate counters, one per (frame, level), lie kCandCounterStride ints apart: every cell of a level adds to
+// its counter once, and same-line atomics are served one after the other (about 9 ns each: with the 8 counters of a
+// frame -- and those of the next frame -- in one line, the 4620 cells of a 1920x1080 frame took 48 us through that
+// queue, two frames 84 us, whatever else the kernel did).
+constexpr int kCandCounterStride = 32;
 __global__ __launch_bounds__(kPyrThreadsMax) void k_copy_level0(const OrbxFrameGeo* __restrict__ geo,
                                                      const uint8_t* __restrict__ images, long long rowStride,
                                                      long long imgStride, uint8_t* __restrict__ pyr,
                                                      long long frameStride, int aligned16, int chunksPerRow,
                                                      int* __restrict__ candCount) {
     const OrbxLevelGeo& D = geo->lv[0];
-    if (blockIdx.x == 0 && threadIdx.x < (unsigned)geo->nlevels) candCount[blockIdx.y * geo->nlevels + threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)geo->nlevels) candCount[(blockIdx.y * geo->nlevels + threadIdx.x) * kCandCounterStride] = 0;
     // the 16-byte chunks of a frame as one sequence: full workgroups whatever the image width
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = i / chunksPerRow;
@@ -792,7 +797,7 @@ __global__ __launch_bounds__(kFastThreads) void k_fast(const OrbxFrameGeo* __res
     const float s = G.scale, inv = G.invScale;
     const float border = (float)kOrbxMinBorder;
     OrbxCand* out = cands + (long long)frame * geo->candTotal + G.candOff;
-    int* counter = candCount + frame * nl + level;
+    int* counter = candCount + (frame * nl + level) * kCandCounterStride;
     // Without erase rectangles every kept corner is emitted, so the cell reserves its output
     // range with ONE global atomic (the per-level counter is shared by hundreds of cells);
     // with rectangles the survivors are not known in advance and each takes its own slot.
@@ -935,7 +940,7 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(const OrbxFrameGeo* __r
     int* tmp = base + cap;          // kQtThreads
     __shared__ int s_size, s_done, s_nExp, s_total, s_careful, s_nE, s_bad;
 
-    const int n = min(candCount[frame * nl + level], G.candCap);
+    const int n = min(candCount[(frame * nl + level) * kCandCounterStride], G.candCap);
     const OrbxCand* C = cands + (long long)frame * geo->candTotal + G.candOff;
     uint16_t* KN = keyNode + (long long)frame * geo->candTotal + G.candOff;
     const int N = G.quota;
@@ -1982,7 +1987,7 @@ struct orbx_extractor {
     OrbxCand* d_cands = nullptr;   size_t candAlloc = 0;
     uint16_t* d_keyNode = nullptr;
     OrbxLevelKp* d_levelKps = nullptr; size_t kpAlloc = 0;
-    int* d_candCount = nullptr;    // max_batch * nlevels
+    int* d_candCount = nullptr;    // max_batch * nlevels counters, kCandCounterStride ints apart
     int* d_kpCount = nullptr;      // max_batch * nlevels
     OrbxErr* d_err = nullptr;
     OrbxErr* h_err = nullptr;      // pinned
@@ -2376,7 +2381,7 @@ extern "C" orbx_status orbx_extractor_create(const orbx_params* p, orbx_extracto
     if (hipStreamCreateWithFlags(&ex->stream, hipStreamNonBlocking) != hipSuccess) { orbx_set_error("hipStreamCreate failed"); return fail(ORBX_ERR_HIP); }
     const size_t B = (size_t)p->max_batch;
     if (hipMalloc((void**)&ex->d_geo, sizeof(OrbxFrameGeo)) != hipSuccess ||
-        hipMalloc((void**)&ex->d_candCount, B * nl * sizeof(int)) != hipSuccess ||
+        hipMalloc((void**)&ex->d_candCount, B * nl * kCandCounterStride * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&ex->d_kpCount, B * nl * sizeof(int)) != hipSuccess ||
         hipMalloc((void**)&ex->d_err, sizeof(OrbxErr)) != hipSuccess ||
         hipMalloc((void**)&ex->d_rects, kOrbxMaxRects * sizeof(orbx_rect)) != hipSuccess ||
@@ -2471,12 +2476,12 @@ static orbx_status enqueue_batch(orbx_extractor* ex, int nf, int lap0, int lap1,
     V.d_cands = ex->d_cands + (size_t)frame0 * g.candTotal;
     V.d_keyNode = ex->d_keyNode + (size_t)frame0 * g.candTotal;
     V.d_levelKps = ex->d_levelKps + (size_t)frame0 * g.kpTotal;
-    V.d_candCount = ex->d_candCount + (size_t)frame0 * nl;
+    V.d_candCount = ex->d_candCount + (size_t)frame0 * nl * kCandCounterStride;
     V.d_kpCount = ex->d_kpCount + (size_t)frame0 * nl;
     V.d_descWork = ex->d_descWork + (size_t)frame0 * g.kpTotal;
     // the only per-batch state that must start at zero; the quadtree writes every keypoint count and
     // the error record is cleared when it is read (orbx_extract_status)
-    if (!countersCleared) ORBX_HIP_TRY(hipMemsetAsync(V.d_candCount, 0, (size_t)nf * nl * sizeof(int), st));
+    if (!countersCleared) ORBX_HIP_TRY(hipMemsetAsync(V.d_candCount, 0, (size_t)nf * nl * kCandCounterStride * sizeof(int), st));
     if (ex->timing && ex->evUsed + kTimedStages + 1 > 4096 * (size_t)(kTimedStages + 1)) resolve_timing(ex);
     mark(ex, st);   // end of copy-in (its start is marked by the caller)
     for (int l = 1; l < nl; ++l) {
@@ -2553,7 +2558,7 @@ static orbx_status enqueue_images(orbx_extractor* ex, const uint8_t* d_images, i
     mark(ex, st);
     hipLaunchKernelGGL(k_copy_level0, grid, dim3(pyrThreads), 0, st, ex->d_geo, d_images, (long long)row_stride,
                        (long long)frame_stride, ex->d_pyr + (size_t)frame0 * ex->geo.pyrBytes, ex->geo.pyrBytes, aligned16,
-                       chunksPerRow, ex->d_candCount + (size_t)frame0 * ex->geo.nlevels);
+                       chunksPerRow, ex->d_candCount + (size_t)frame0 * ex->geo.nlevels * kCandCounterStride);
     return enqueue_batch(ex, n_frames, lap0, lap1, dyn_host, ndyn, d_keypoints, d_descriptors, capacity, d_counts, st, true, frame0);
 }
 
@@ -3017,7 +3022,7 @@ extern "C" orbx_status orbx_debug_level_candidates(orbx_extractor* ex, int frame
     ORBX_HIP_TRY(hipSetDevice(ex->device));
     ORBX_HIP_TRY(hipDeviceSynchronize());
     int n = 0;
-    ORBX_HIP_TRY(hipMemcpy(&n, ex->d_candCount + frame * ex->geo.nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    ORBX_HIP_TRY(hipMemcpy(&n, ex->d_candCount + ((size_t)frame * ex->geo.nlevels + level) * kCandCounterStride, sizeof(int), hipMemcpyDeviceToHost));
     const OrbxLevelGeo& L = ex->geo.lv[level];
     n = std::min(n, L.candCap);
     *n_out = n;
