@@ -193,6 +193,41 @@ def dry_world(A, torch, dev, world, batch, n_map=200_003, n_query=1000):
             "note": "rank-by-rank on one GPU; no collective involved"}
 
 
+def issue_ceiling(config, frames_per_launch):
+    """Issue-bound ceiling of the extraction from committed counter passes (profiles/<tag>_extract_<config>_pmc_sq.csv:
+    SQ_INSTS_VALU / SQ_INSTS_SALU per kernel and launch) and the measured issue costs (profiles/r03_issue_model.json);
+    None when the files are missing."""
+    import csv
+    for tag in ("r03", "r02"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{tag}_extract_{config}_pmc_sq.csv")) as f:
+                rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
+            with open(os.path.join(ROOT, "profiles", "r03_issue_model.json")) as f:
+                model = json.load(f)
+            per_kernel, total_ns = {}, 0.0
+            for r in rows:
+                k = r["kernel"]
+                launches = NLEVELS - 1 if k == "k_resize" else 1
+                nv, ns = float(r["SQ_INSTS_VALU"]) * launches, float(r["SQ_INSTS_SALU"]) * launches
+                # (the quadtree's instruction mix does not depend on its workgroup size)
+                kk = "k_quadtree<128>" if k.startswith("k_quadtree") else k
+                cv = model["kernels"].get(kk, {}).get("mean_valu_cost_ns", model["valu_cost_ns_default"])
+                ns_total = nv * cv + ns * model["salu_cost_ns"]
+                per_kernel[k] = {"valu": nv, "salu": ns, "mean_valu_cost_ns": cv,
+                                 f"issue_us_per_{frames_per_launch}_frames": ns_total / model["simds"] / 1e3}
+                total_ns += ns_total
+            ceiling = frames_per_launch / (total_ns / model["simds"] * 1e-9)
+            return {f"per_kernel_per_{frames_per_launch}_frames": per_kernel, "salu_cost_ns": model["salu_cost_ns"],
+                    f"issue_us_per_{frames_per_launch}_frames": total_ns / model["simds"] / 1e3,
+                    "ceiling_frames_per_s": ceiling,
+                    "source": f"committed profiles profiles/{tag}_extract_{config}_pmc_sq.csv (instruction counts; not measured "
+                              "by this run) and profiles/r03_issue_model.json (costs); extraction kernels only, the stereo "
+                              "matcher's kernels are not charged"}
+        except (OSError, KeyError, ValueError):
+            pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -446,33 +481,7 @@ def main():
     # issues it (profiles/<tag>_issue_model.json: per-kernel mean cost of a vector instruction from the kernel's
     # instruction mix x the measured cost of each class; marginal cost of a scalar instruction), all 1024 SIMDs busy all
     # the time.  Memory instructions, waits and barriers are not charged: a ceiling, not a prediction.
-    valu = None
-    for tag in ("r03", "r02"):
-        try:
-            import csv
-            with open(os.path.join(ROOT, "profiles", f"{tag}_extract_euroc_b64_pmc_sq.csv")) as f:
-                rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
-            with open(os.path.join(ROOT, "profiles", "r03_issue_model.json")) as f:
-                model = json.load(f)
-            per_kernel, total_ns = {}, 0.0
-            for r in rows:
-                k = r["kernel"]
-                launches = NLEVELS - 1 if k == "k_resize" else 1
-                nv, ns = float(r["SQ_INSTS_VALU"]) * launches, float(r["SQ_INSTS_SALU"]) * launches
-                cv = model["kernels"].get(k, {}).get("mean_valu_cost_ns", model["valu_cost_ns_default"])
-                ns_total = nv * cv + ns * model["salu_cost_ns"]
-                per_kernel[k] = {"valu": nv, "salu": ns, "mean_valu_cost_ns": cv,
-                                 "issue_us_per_64_frames": ns_total / model["simds"] / 1e3}
-                total_ns += ns_total
-            ceiling = 64.0 / (total_ns / model["simds"] * 1e-9)
-            valu = {"per_kernel_per_64_frames": per_kernel, "salu_cost_ns": model["salu_cost_ns"],
-                    "issue_us_per_64_frames": total_ns / model["simds"] / 1e3, "ceiling_frames_per_s": ceiling,
-                    "source": f"committed profiles profiles/{tag}_extract_euroc_b64_pmc_sq.csv (instruction counts; not measured by "
-                              "this run) and profiles/r03_issue_model.json (costs); extraction kernels only, the stereo matcher's "
-                              "kernels are not charged"}
-            break
-        except (OSError, KeyError, ValueError):
-            pass
+    valu = issue_ceiling("euroc_b64", 64)
     fast_s = stage_ms["fast"] * 1e-3
     achieved = fast_bytes / fast_s / 1e9 if fast_s > 0 else 0.0
     frame_bytes = W * H + px + 60 * n_kp                                   # input + pyramid + keypoints/descriptors
@@ -596,6 +605,10 @@ def main():
                               "frac": fpsH / world * bytesH / 1e9 / HBM_PEAK_GBS},
             "stage_ms_per_launch": {k: tH[k] / max(nH, 1) for k in tH},
             "scaling": "weak"}
+        ib = issue_ceiling("1080p_b32", 32)
+        if ib is not None:
+            ib["frac_of_ceiling"] = fpsH / world / ib["ceiling_frames_per_s"]
+            out["extract_1080p"]["issue_bound"] = ib
         del exs, exH, outs, outH, dF
         torch.cuda.empty_cache()
 
