@@ -1,8 +1,9 @@
 """Who runs beside whom: concurrency analysis of a rocprofv3 kernel trace (CSV) of a multi-stream run.
 
-    python3 tools/kernel_overlap.py <..._kernel_trace.csv> [skip_fraction]
+    python3 tools/kernel_overlap.py <..._kernel_trace.csv> [skip_fraction] [end_fraction]
 
-Over the window that starts after the first `skip_fraction` (default 0.4) of the dispatches: the share of the time with
+Over the window that starts after the first `skip_fraction` (default 0.4) of the dispatches (and ends at `end_fraction`
+of them, default 1): the share of the time with
 0, 1, 2, ... kernels in flight, the share with at least one of the issue-bound kernels (k_fast, k_describe) in flight, and
 per kernel name the mean duration in this run (stretched by its neighbours) and the share of its time it ran alone."""
 import csv
@@ -17,10 +18,10 @@ def short(n):
     return n.split("<")[0] if n.startswith("k_") else n[:28]
 
 
-def main(path, skip=0.4):
+def main(path, skip=0.4, end=1.0):
     rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in csv.DictReader(open(path))]
     rows.sort()
-    rows = rows[int(len(rows) * skip):]
+    rows = rows[int(len(rows) * skip):int(len(rows) * end)]
     t0, t1 = rows[0][0], max(r[1] for r in rows)
     ev = []
     for i, (s, e, n) in enumerate(rows):
@@ -57,4 +58,4 @@ def main(path, skip=0.4):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.4)
+    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 0.4, float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)
