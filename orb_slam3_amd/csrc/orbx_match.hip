@@ -216,7 +216,7 @@ extern "C" orbx_status orbx_descriptor_distance(const uint8_t* a, const uint8_t*
 // running best / second best.  Train descriptors are wave-uniform: they are fetched with
 // scalar loads and applied to all 64 x kQpl queries of the wave, so the inner loop is
 // 8 x (v_xor_b32 with an SGPR operand + v_bcnt_u32_b32 accumulate) per pair and one compare.
-// The train set is cut into spans of kKnnSpanRows rows.  grid.y = the workers of a query group, as many as
+// The train set is cut into spans of kKnnSpanRows rows (fewer for a small set: knn2_span_rows).  grid.y = the workers of a query group, as many as
 // fill the chip once; a worker (one wave) takes the next unclaimed span of its query group from a counter until
 // none is left, so waves that the SIMD's arbitration favours simply take more spans and all of them finish
 // within one span of each other (with one fixed slice per wave the slowest wave of a SIMD ran its last third
@@ -228,7 +228,8 @@ extern "C" orbx_status orbx_descriptor_distance(const uint8_t* a, const uint8_t*
 constexpr int kQpl = 4;        // queries per lane
 constexpr int kKnnWaves = 4;
 constexpr int kRowsPerIter = 8;   // train rows fetched (scalar) and applied per loop trip
-constexpr int kKnnSpanRows = 2048;   // rows a worker claims at a time (a multiple of kRowsPerIter)
+constexpr int kKnnSpanRows = 2048;   // most rows a worker claims at a time (a multiple of kRowsPerIter)
+constexpr int kKnnMinSpanRows = 32;  // fewest: a small train set is cut into this many rows per span so that more than one wave per query group works on it
 
 // Per-query register state.  Four named instances (not an array) so that everything stays in
 // VGPRs: a runtime-indexed array of these would be placed in scratch memory.
@@ -344,7 +345,7 @@ __device__ __forceinline__ void knn_store(const KnnQuery& s, int nq, orbx_match2
 
 __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restrict__ query, int nq,
                                                           const uint32_t* __restrict__ train, long long nt,
-                                                          int nSpans, long long baseIndex,
+                                                          int nSpans, int spanRows, long long baseIndex,
                                                           orbx_match2* __restrict__ part, int* __restrict__ spanCounter) {
     static_assert(kQpl == 4 && kRowsPerIter == 8, "the body below is written out for 4 queries x 2 groups of 4 rows");
     static_assert(kKnnSpanRows % kRowsPerIter == 0, "a span is a whole number of loop trips");
@@ -369,8 +370,8 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint32_t* __restr
     if (lane == 0) span = atomicAdd(&spanCounter[group], 1);
     span = __builtin_amdgcn_readfirstlane(span);
     if (span >= nSpans) break;
-    const long long j0 = (long long)span * kKnnSpanRows;
-    const long long j1 = min(nt, j0 + kKnnSpanRows);
+    const long long j0 = (long long)span * spanRows;
+    const long long j1 = min(nt, j0 + spanRows);
     long long j = j0;
     // 8 rows per trip, fetched as two groups of 4: the scalar loads of the second group are in flight
     // while the first group is applied, and the next trip's first group while the second is applied
@@ -477,14 +478,25 @@ static int knn2_resident_blocks() {
     return v;
 }
 
-// Workers (grid.y) per query group: one resident round of the chip and no more -- a grid a few workgroups larger
-// than what fits at once leaves those to start after everything else has finished -- and no more workers than spans.
-static int knn2_chunks(int nq, long long nt) {
+// Workers (grid.y) the chip holds per query group: one resident round and no more -- a grid a few workgroups larger
+// than what fits at once leaves those to start after everything else has finished.
+static long long knn2_workers_wanted(int nq) {
     const int groups = (nq + 64 * kQpl - 1) / (64 * kQpl);
     const int blocksPerChunk = (groups + kKnnWaves - 1) / kKnnWaves;
-    long long want = std::max(1, knn2_resident_blocks() / std::max(blocksPerChunk, 1));
-    long long spans = std::max<long long>(1, (nt + kKnnSpanRows - 1) / kKnnSpanRows);
-    long long c = std::max<long long>(1, std::min(want, spans));
+    return std::max(1, knn2_resident_blocks() / std::max(blocksPerChunk, 1));
+}
+// Rows per span: kKnnSpanRows for a large train set; a train set too small to give every wanted worker such a span
+// is cut finer (down to kKnnMinSpanRows), or a 1000 x 1000 search would be one wave per 256 queries walking all rows.
+static int knn2_span_rows(int nq, long long nt) {
+    const long long per = (nt + knn2_workers_wanted(nq) - 1) / knn2_workers_wanted(nq);
+    const long long rows = (per + kRowsPerIter - 1) / kRowsPerIter * kRowsPerIter;
+    return (int)std::min<long long>(kKnnSpanRows, std::max<long long>(kKnnMinSpanRows, rows));
+}
+// ... and no more workers than spans.
+static int knn2_chunks(int nq, long long nt) {
+    const int spanRows = knn2_span_rows(nq, nt);
+    long long spans = std::max<long long>(1, (nt + spanRows - 1) / spanRows);
+    long long c = std::max<long long>(1, std::min(knn2_workers_wanted(nq), spans));
     return (int)std::min<long long>(c, 4096);
 }
 static int knn2_groups(int nq) { return (nq + 64 * kQpl - 1) / (64 * kQpl); }
@@ -502,11 +514,12 @@ extern "C" size_t orbx_knn2_workspace_bytes(int n_query, int64_t n_train) {
 static void knn2_launch(const uint8_t* d_query, int n_query, const uint8_t* d_train, int64_t n_train, int64_t base_index,
                         int workers, orbx_match2* parts, int* counters, hipStream_t st) {
     const int groups = knn2_groups(n_query);
-    const int nSpans = (int)((n_train + kKnnSpanRows - 1) / kKnnSpanRows);
+    const int spanRows = knn2_span_rows(n_query, n_train);
+    const int nSpans = (int)((n_train + spanRows - 1) / spanRows);
     (void)hipMemsetAsync(counters, 0, (size_t)groups * sizeof(int), st);
     dim3 grid((groups + kKnnWaves - 1) / kKnnWaves, workers);
     hipLaunchKernelGGL(k_knn2, grid, dim3(64 * kKnnWaves), 0, st, (const uint32_t*)d_query, n_query, (const uint32_t*)d_train,
-                       (long long)n_train, nSpans, (long long)base_index, parts, counters);
+                       (long long)n_train, nSpans, spanRows, (long long)base_index, parts, counters);
 }
 
 extern "C" orbx_status orbx_hamming_knn2_device(const uint8_t* d_query, int n_query, const uint8_t* d_train,
