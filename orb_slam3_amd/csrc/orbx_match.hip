@@ -1063,28 +1063,39 @@ extern "C" orbx_status orbx_stereo_match(orbx_extractor* left, orbx_extractor* r
     ORBX_REQUIRE(kps_left && desc_left && u_right && depth && (n_right == 0 || (kps_right && desc_right)), "null argument");
     ORBX_HIP_TRY(hipSetDevice(orbx_internal_device(left)));
     const int cap = std::max(std::max(n_left, n_right), 1);
-    DevBuf kl, dl, kr, dr, cl, cr, ur, dp;
-    ORBX_HIP_TRY(kl.alloc((size_t)cap * sizeof(orbx_keypoint))); ORBX_HIP_TRY(dl.alloc((size_t)cap * 32));
-    ORBX_HIP_TRY(kr.alloc((size_t)cap * sizeof(orbx_keypoint))); ORBX_HIP_TRY(dr.alloc((size_t)cap * 32));
-    ORBX_HIP_TRY(cl.alloc(8)); ORBX_HIP_TRY(cr.alloc(8));
-    ORBX_HIP_TRY(ur.alloc((size_t)cap * 4)); ORBX_HIP_TRY(dp.alloc((size_t)cap * 4));
-    const int cL[2] = {n_left, 0}, cR[2] = {n_right, 0};
-    hipStream_t st = orbx_internal_stream(left);      // uploads, kernels and downloads in one stream
-    ORBX_HIP_TRY(copy_sync(kl.p, kps_left, (size_t)n_left * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(dl.p, desc_left, (size_t)n_left * 32, hipMemcpyHostToDevice, st));
+    // One upload and one download: the inputs are packed into the calling thread's pinned arena (pageable copies of a
+    // few dozen KB each cost 10-15 us apiece; eight of them were two thirds of this call), the results come back
+    // through it.
+    const size_t kb = (size_t)cap * sizeof(orbx_keypoint), db = (size_t)cap * 32, fb = align256((size_t)cap * 4);
+    const size_t oKL = 0, oDL = align256(kb), oKR = align256(oDL + db), oDR = align256(oKR + kb), oC = align256(oDR + db);
+    const size_t inBytes = oC + 256, oOut = inBytes;
+    ORBX_HIP_TRY(t_arena.ensure(oOut + 2 * fb));
+    DevBuf in, out;
+    ORBX_HIP_TRY(in.alloc(inBytes)); ORBX_HIP_TRY(out.alloc(2 * fb));
+    char* h = t_arena.host;
+    memcpy(h + oKL, kps_left, (size_t)n_left * sizeof(orbx_keypoint));
+    memcpy(h + oDL, desc_left, (size_t)n_left * 32);
     if (n_right) {
-        ORBX_HIP_TRY(copy_sync(kr.p, kps_right, (size_t)n_right * sizeof(orbx_keypoint), hipMemcpyHostToDevice, st));
-        ORBX_HIP_TRY(copy_sync(dr.p, desc_right, (size_t)n_right * 32, hipMemcpyHostToDevice, st));
+        memcpy(h + oKR, kps_right, (size_t)n_right * sizeof(orbx_keypoint));
+        memcpy(h + oDR, desc_right, (size_t)n_right * 32);
     }
-    ORBX_HIP_TRY(copy_sync(cl.p, cL, 8, hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(cr.p, cR, 8, hipMemcpyHostToDevice, st));
+    const int counts[4] = {n_left, 0, n_right, 0};
+    memcpy(h + oC, counts, sizeof(counts));
+    hipStream_t st = orbx_internal_stream(left);      // upload, kernels and download in one stream
+    ORBX_HIP_TRY(hipMemcpyAsync(in.p, h, inBytes, hipMemcpyHostToDevice, st));
     ORBX_HIP_TRY(hipStreamSynchronize(orbx_internal_stream(right)));   // the right pyramid was built on its own stream
-    orbx_status s = orbx_stereo_match_batch_device(left, right, 1, kl.as<orbx_keypoint>(), dl.as<uint8_t>(), cl.as<int>(),
-                                                   kr.as<orbx_keypoint>(), dr.as<uint8_t>(), cr.as<int>(), cap, mbf, mb,
-                                                   ur.as<float>(), dp.as<float>(), st);
+    char* d = in.as<char>();
+    float* dUr = out.as<float>();
+    float* dDp = reinterpret_cast<float*>(out.as<char>() + fb);
+    orbx_status s = orbx_stereo_match_batch_device(left, right, 1, reinterpret_cast<orbx_keypoint*>(d + oKL),
+                                                   reinterpret_cast<uint8_t*>(d + oDL), reinterpret_cast<int*>(d + oC),
+                                                   reinterpret_cast<orbx_keypoint*>(d + oKR), reinterpret_cast<uint8_t*>(d + oDR),
+                                                   reinterpret_cast<int*>(d + oC) + 2, cap, mbf, mb, dUr, dDp, st);
     if (s != ORBX_OK) return s;
-    ORBX_HIP_TRY(copy_sync(u_right, ur.p, (size_t)n_left * 4, hipMemcpyDeviceToHost, st));
-    ORBX_HIP_TRY(copy_sync(depth, dp.p, (size_t)n_left * 4, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_TRY(hipMemcpyAsync(h + oOut, out.p, 2 * fb, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_TRY(hipStreamSynchronize(st));
+    memcpy(u_right, h + oOut, (size_t)n_left * 4);
+    memcpy(depth, h + oOut + fb, (size_t)n_left * 4);
     return ORBX_OK;
 }
 
