@@ -157,6 +157,46 @@ hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kin
     if (e != hipSuccess || kind != hipMemcpyDeviceToHost) return e;
     return hipStreamSynchronize(st);
 }
+
+// Several small host arrays in ONE upload and several small results in ONE download, both through the calling
+// thread's pinned arena (a copy from or to pageable memory costs 10-15 us per command whatever its size).
+// add() / want() lay the arrays out (256-byte aligned) and return their offsets; upload() packs and enqueues the
+// host-to-device copy into `in`; download() enqueues the copy of `out` back, waits for the stream and hands out
+// the results with fetch().
+struct PackedIo {
+    struct Item { const void* src; size_t bytes, off; };
+    std::vector<Item> ups;
+    size_t upBytes = 0, downBytes = 0;
+    DevBuf in, out;
+    size_t add(const void* src, size_t bytes) {
+        const size_t off = upBytes;
+        ups.push_back({src, bytes, off});
+        upBytes = align256(upBytes + std::max<size_t>(bytes, 1));
+        return off;
+    }
+    size_t want(size_t bytes) {
+        const size_t off = downBytes;
+        downBytes = align256(downBytes + std::max<size_t>(bytes, 1));
+        return off;
+    }
+    hipError_t upload(hipStream_t st) {
+        hipError_t e = t_arena.ensure(upBytes + downBytes);
+        if (e != hipSuccess) return e;
+        for (const Item& it : ups)
+            if (it.bytes) memcpy(t_arena.host + it.off, it.src, it.bytes);
+        if ((e = in.alloc(std::max<size_t>(upBytes, 256))) != hipSuccess) return e;
+        if ((e = out.alloc(std::max<size_t>(downBytes, 256))) != hipSuccess) return e;
+        return hipMemcpyAsync(in.p, t_arena.host, upBytes, hipMemcpyHostToDevice, st);
+    }
+    template <class T> T* dev_in(size_t off) { return reinterpret_cast<T*>(in.as<char>() + off); }
+    template <class T> T* dev_out(size_t off) { return reinterpret_cast<T*>(out.as<char>() + off); }
+    hipError_t download(hipStream_t st) {
+        hipError_t e = hipMemcpyAsync(t_arena.host + upBytes, out.p, downBytes, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return e;
+        return hipStreamSynchronize(st);
+    }
+    void fetch(void* dst, size_t off, size_t bytes) const { if (bytes) memcpy(dst, t_arena.host + upBytes + off, bytes); }
+};
 }  // namespace
 
 static void release_thread_staging();   // the pinned arena and the scratch frames of the windowed searches
@@ -198,14 +238,14 @@ extern "C" orbx_status orbx_descriptor_distance(const uint8_t* a, const uint8_t*
     if (n == 0) return ORBX_OK;
     hipStream_t st;
     ORBX_HIP_TRY(thread_stream(&st));
-    DevBuf da, db, dout;
-    ORBX_HIP_TRY(da.alloc((size_t)n * 32)); ORBX_HIP_TRY(db.alloc((size_t)n * 32)); ORBX_HIP_TRY(dout.alloc((size_t)n * 4));
-    ORBX_HIP_TRY(copy_sync(da.p, a, (size_t)n * 32, hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(db.p, b, (size_t)n * 32, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_pair_distance, dim3((n + 255) / 256), dim3(256), 0, st, da.as<uint32_t>(), db.as<uint32_t>(), n,
-                       dout.as<int>());
+    PackedIo io;
+    const size_t oA = io.add(a, (size_t)n * 32), oB = io.add(b, (size_t)n * 32), oOut = io.want((size_t)n * 4);
+    ORBX_HIP_TRY(io.upload(st));
+    hipLaunchKernelGGL(k_pair_distance, dim3((n + 255) / 256), dim3(256), 0, st, io.dev_in<uint32_t>(oA), io.dev_in<uint32_t>(oB), n,
+                       io.dev_out<int>(oOut));
     ORBX_HIP_TRY(hipGetLastError());
-    ORBX_HIP_TRY(copy_sync(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_TRY(io.download(st));
+    io.fetch(out, oOut, (size_t)n * 4);
     return ORBX_OK;
 }
 
@@ -1857,23 +1897,20 @@ extern "C" orbx_status orbx_bucket_best(const uint8_t* desc1, int n_desc1, const
     for (int j = 0; j < n2; ++j) ORBX_REQUIRE(idx2[j] >= 0 && idx2[j] < n_desc2, "idx2 out of range");
     hipStream_t st;
     ORBX_HIP_TRY(thread_stream(&st));
-    DevBuf D1, D2, I1, I2, O1, O2, BO, BI, BD;
-    ORBX_HIP_TRY(D1.alloc((size_t)n_desc1 * 32)); ORBX_HIP_TRY(D2.alloc((size_t)n_desc2 * 32));
-    ORBX_HIP_TRY(I1.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(I2.alloc((size_t)n2 * 4));
-    ORBX_HIP_TRY(O1.alloc((size_t)(n_buckets + 1) * 4)); ORBX_HIP_TRY(O2.alloc((size_t)(n_buckets + 1) * 4));
-    ORBX_HIP_TRY(BO.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(BI.alloc((size_t)n1 * 4)); ORBX_HIP_TRY(BD.alloc((size_t)n1 * 4));
-    ORBX_HIP_TRY(copy_sync(D1.p, desc1, (size_t)n_desc1 * 32, hipMemcpyHostToDevice, st));
-    if (n_desc2) ORBX_HIP_TRY(copy_sync(D2.p, desc2, (size_t)n_desc2 * 32, hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(I1.p, idx1, (size_t)n1 * 4, hipMemcpyHostToDevice, st));
-    if (n2) ORBX_HIP_TRY(copy_sync(I2.p, idx2, (size_t)n2 * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(O1.p, off1, (size_t)(n_buckets + 1) * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(O2.p, off2, (size_t)(n_buckets + 1) * 4, hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(BO.p, bucketOf.data(), (size_t)n1 * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_bucket_best, dim3((n1 + 3) / 4), dim3(256), 0, st, D1.as<uint32_t>(), I1.as<int>(), O1.as<int>(),
-                       D2.as<uint32_t>(), I2.as<int>(), O2.as<int>(), BO.as<int>(), n1, BI.as<int>(), BD.as<int>());
+    PackedIo io;
+    const size_t oD1 = io.add(desc1, (size_t)n_desc1 * 32), oD2 = io.add(desc2, (size_t)n_desc2 * 32);
+    const size_t oI1 = io.add(idx1, (size_t)n1 * 4), oI2 = io.add(idx2, (size_t)n2 * 4);
+    const size_t oO1 = io.add(off1, (size_t)(n_buckets + 1) * 4), oO2 = io.add(off2, (size_t)(n_buckets + 1) * 4);
+    const size_t oBO = io.add(bucketOf.data(), (size_t)n1 * 4);
+    const size_t oBI = io.want((size_t)n1 * 4), oBD = io.want((size_t)n1 * 4);
+    ORBX_HIP_TRY(io.upload(st));
+    hipLaunchKernelGGL(k_bucket_best, dim3((n1 + 3) / 4), dim3(256), 0, st, io.dev_in<uint32_t>(oD1), io.dev_in<int>(oI1),
+                       io.dev_in<int>(oO1), io.dev_in<uint32_t>(oD2), io.dev_in<int>(oI2), io.dev_in<int>(oO2),
+                       io.dev_in<int>(oBO), n1, io.dev_out<int>(oBI), io.dev_out<int>(oBD));
     ORBX_HIP_TRY(hipGetLastError());
-    ORBX_HIP_TRY(copy_sync(best_idx2, BI.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
-    ORBX_HIP_TRY(copy_sync(best_dist, BD.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_TRY(io.download(st));
+    io.fetch(best_idx2, oBI, (size_t)n1 * 4);
+    io.fetch(best_dist, oBD, (size_t)n1 * 4);
     return ORBX_OK;
 }
 
@@ -2848,16 +2885,17 @@ extern "C" orbx_status orbx_bow_transform(orbx_vocabulary* voc, const uint8_t* d
     ORBX_HIP_TRY(hipSetDevice(voc->device));
     hipStream_t st;
     ORBX_HIP_TRY(thread_stream(&st));
-    DevBuf dd, dl, dn;
-    ORBX_HIP_TRY(dd.alloc((size_t)n * 32)); ORBX_HIP_TRY(dl.alloc((size_t)n * 4)); ORBX_HIP_TRY(dn.alloc((size_t)n * 4));
-    ORBX_HIP_TRY(copy_sync(dd.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    PackedIo io;
+    const size_t oD = io.add(desc, (size_t)n * 32), oL = io.want((size_t)n * 4), oN = io.want((size_t)n * 4);
+    ORBX_HIP_TRY(io.upload(st));
     const int nidLevel = voc->depth - levelsup;     // <= 0: the feature vector node is the root
     hipLaunchKernelGGL(k_bow_descend, dim3((n + 3) / 4), dim3(256), 0, st, voc->d_childOff, voc->d_childIdx, voc->d_desc,
-                       dd.as<uint32_t>(), n, nidLevel, dl.as<int>(), dn.as<int>());
+                       io.dev_in<uint32_t>(oD), n, nidLevel, io.dev_out<int>(oL), io.dev_out<int>(oN));
     ORBX_HIP_TRY(hipGetLastError());
+    ORBX_HIP_TRY(io.download(st));
     std::vector<int> leaf(n);
-    ORBX_HIP_TRY(copy_sync(leaf.data(), dl.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    ORBX_HIP_TRY(copy_sync(node_id, dn.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    io.fetch(leaf.data(), oL, (size_t)n * 4);
+    io.fetch(node_id, oN, (size_t)n * 4);
     for (int i = 0; i < n; ++i) { word_id[i] = voc->wordId[leaf[i]]; weight[i] = voc->weight[leaf[i]]; }
     return ORBX_OK;
 }
@@ -2970,17 +3008,17 @@ extern "C" orbx_status orbx_distinctive_descriptors(const uint8_t* desc, const i
     ORBX_REQUIRE(total == 0 || desc, "null descriptors");
     hipStream_t st;
     ORBX_HIP_TRY(thread_stream(&st));
-    DevBuf dD, dO, dI, dM;
-    ORBX_HIP_TRY(dD.alloc((size_t)std::max(total, 1) * 32)); ORBX_HIP_TRY(dO.alloc((size_t)(n_points + 1) * 4));
-    ORBX_HIP_TRY(dI.alloc((size_t)n_points * 4)); ORBX_HIP_TRY(dM.alloc((size_t)n_points * 4));
-    if (total) ORBX_HIP_TRY(copy_sync(dD.p, desc, (size_t)total * 32, hipMemcpyHostToDevice, st));
-    ORBX_HIP_TRY(copy_sync(dO.p, off, (size_t)(n_points + 1) * 4, hipMemcpyHostToDevice, st));
+    PackedIo io;
+    const size_t oD = io.add(desc, (size_t)total * 32), oO = io.add(off, (size_t)(n_points + 1) * 4);
+    const size_t oI = io.want((size_t)n_points * 4), oM = io.want((size_t)n_points * 4);
+    ORBX_HIP_TRY(io.upload(st));
     maxN = (maxN + 1) & ~1;
     const size_t lds = (size_t)maxN * 32 + (size_t)64 * maxN * 2;      // <= 61440 bytes at 384 observations
-    hipLaunchKernelGGL(k_distinctive, dim3(n_points), dim3(64), lds, st, dD.as<uint32_t>(), dO.as<int>(), dI.as<int>(),
-                       dM.as<int>(), maxN);
+    hipLaunchKernelGGL(k_distinctive, dim3(n_points), dim3(64), lds, st, io.dev_in<uint32_t>(oD), io.dev_in<int>(oO),
+                       io.dev_out<int>(oI), io.dev_out<int>(oM), maxN);
     ORBX_HIP_TRY(hipGetLastError());
-    ORBX_HIP_TRY(copy_sync(best_idx, dI.p, (size_t)n_points * 4, hipMemcpyDeviceToHost, st));
-    ORBX_HIP_TRY(copy_sync(best_median, dM.p, (size_t)n_points * 4, hipMemcpyDeviceToHost, st));
+    ORBX_HIP_TRY(io.download(st));
+    io.fetch(best_idx, oI, (size_t)n_points * 4);
+    io.fetch(best_median, oM, (size_t)n_points * 4);
     return ORBX_OK;
 }

@@ -2,7 +2,8 @@
 """Moves the line citations of oracle/AUDIT.md (O: oracle, A: binding, L: library) along with the files they point into.
     python3 tools/audit_renumber.py [<commit>]
 <commit> (default: the last commit that touched oracle/AUDIT.md) is a state in which the citations were right; every
-cited line is followed through difflib's matching of that version of the file against the working tree.  A citation
+cited line is followed through difflib's matching of that version of the file against the working tree (the
+citations are taken from that commit's AUDIT.md, so the tool can be run any number of times before committing).  A citation
 whose line was itself changed is reported and left alone (tests/test_oracle_audit.py will point at it)."""
 import difflib
 import os
@@ -21,7 +22,10 @@ def git(*a):
 def main():
     commit = sys.argv[1] if len(sys.argv) > 1 else git("log", "-n", "1", "--format=%H", "--", "oracle/AUDIT.md").strip()
     audit_path = os.path.join(ROOT, "oracle", "AUDIT.md")
-    audit = open(audit_path, encoding="utf-8").read()
+    # always from the committed text, so that a second run on the same working tree does not move the citations twice
+    audit = git("show", f"{commit}:oracle/AUDIT.md")
+    if open(audit_path, encoding="utf-8").read() != audit:
+        print("note: oracle/AUDIT.md differs from its committed text; rewriting it from the committed text")
     maps = {}
     for tag, path in FILES.items():
         old = git("show", f"{commit}:{path}").split("\n")
