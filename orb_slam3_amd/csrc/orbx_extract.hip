@@ -2658,6 +2658,7 @@ static orbx_status ensure_host_staging(orbx_extractor* ex) {
 }
 
 static int host_chunk_frames(size_t frameBytes, int n_frames);
+constexpr int kHostDirectOutFrames = 2;   // host calls of up to this many frames let the kernels write the pinned result arrays
 static orbx_status extract_host_pipelined(orbx_extractor* ex, const uint8_t* const* images, int n_frames, int width,
                                           int height, ptrdiff_t stride, int lap0, int lap1, orbx_keypoint* keypoints,
                                           uint8_t* descriptors, int capacity, int* n_out, int* mono_index_out);
@@ -2700,16 +2701,24 @@ static orbx_status extract_host(orbx_extractor* ex, const uint8_t* const* images
         else for (int y = 0; y < height; ++y) memcpy(dst + (size_t)y * width, images[f] + (ptrdiff_t)y * stride, width);
     }
     const size_t B = (size_t)n_frames;
+    // One or two frames: k_describe writes its keypoint and descriptor rows straight into the pinned result arrays
+    // (hipHostMalloc memory is visible to the device under the same address), 60 KB per frame in 28- and 32-byte stores,
+    // instead of into device arrays that two copy commands then bring over: a call of this size is a chain of ~18
+    // dependent commands whose submission costs more than their execution, and each command less counts.
+    const bool directOut = n_frames <= kHostDirectOutFrames && !getenv("ORBX_HOST_NO_DIRECT_OUT");
     // upload, every kernel, the downloads and the error record, in stream order
     auto enqueue_all = [&]() -> orbx_status {
         ORBX_HIP_TRY(hipMemcpyAsync(ex->d_in, ex->h_in, B * frameBytes, hipMemcpyHostToDevice, ex->stream));
         orbx_status e = orbx_extract_batch_device(ex, ex->d_in, n_frames, width, height, width, (ptrdiff_t)frameBytes, lap0,
-                                                  lap1, dyn, ndyn, ex->d_outKps, ex->d_outDesc, ex->outCap, ex->d_counts,
+                                                  lap1, dyn, ndyn, directOut ? ex->h_outKps : ex->d_outKps,
+                                                  directOut ? ex->h_outDesc : ex->d_outDesc, ex->outCap, ex->d_counts,
                                                   ex->stream);
         if (e != ORBX_OK) return e;
         ORBX_HIP_TRY(hipMemcpyAsync(ex->h_counts, ex->d_counts, B * 2 * sizeof(int), hipMemcpyDeviceToHost, ex->stream));
-        ORBX_HIP_TRY(hipMemcpyAsync(ex->h_outKps, ex->d_outKps, B * ex->outCap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, ex->stream));
-        ORBX_HIP_TRY(hipMemcpyAsync(ex->h_outDesc, ex->d_outDesc, B * ex->outCap * 32, hipMemcpyDeviceToHost, ex->stream));
+        if (!directOut) {
+            ORBX_HIP_TRY(hipMemcpyAsync(ex->h_outKps, ex->d_outKps, B * ex->outCap * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, ex->stream));
+            ORBX_HIP_TRY(hipMemcpyAsync(ex->h_outDesc, ex->d_outDesc, B * ex->outCap * 32, hipMemcpyDeviceToHost, ex->stream));
+        }
         ORBX_HIP_TRY(hipMemcpyAsync(ex->h_err, ex->d_err, sizeof(OrbxErr), hipMemcpyDeviceToHost, ex->stream));
         return ORBX_OK;
     };
