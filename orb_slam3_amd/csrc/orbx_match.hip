@@ -1584,9 +1584,20 @@ orbx_status frame_assign(orbx_frame& F, const orbx_keypoint* kps, const uint8_t*
     if (uright) ORBX_HIP_TRY(F.uright.ensure((size_t)std::max(n, 1) * 4));
     if (n > 0) {
         const hipMemcpyKind kind = fromDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-        ORBX_HIP_TRY(hipMemcpyAsync(F.kps.p, kps, (size_t)n * sizeof(orbx_keypoint), kind, st));
-        ORBX_HIP_TRY(hipMemcpyAsync(F.desc.p, desc, (size_t)n * 32, kind, st));
-        if (uright) ORBX_HIP_TRY(hipMemcpyAsync(F.uright.p, uright, (size_t)n * 4, kind, st));
+        const void *srcK = kps, *srcD = desc, *srcU = uright;
+        if (!fromDevice) {
+            // host arrays go through the thread's pinned arena: an upload from pageable memory is staged by the
+            // runtime at 10-15 us per command, one from pinned memory is enqueued in 2-3
+            const size_t oD = align256((size_t)n * sizeof(orbx_keypoint)), oU = align256(oD + (size_t)n * 32);
+            ORBX_HIP_TRY(t_arena.ensure(oU + (size_t)n * 4));
+            memcpy(t_arena.host, kps, (size_t)n * sizeof(orbx_keypoint));
+            memcpy(t_arena.host + oD, desc, (size_t)n * 32);
+            if (uright) memcpy(t_arena.host + oU, uright, (size_t)n * 4);
+            srcK = t_arena.host; srcD = t_arena.host + oD; srcU = t_arena.host + oU;
+        }
+        ORBX_HIP_TRY(hipMemcpyAsync(F.kps.p, srcK, (size_t)n * sizeof(orbx_keypoint), kind, st));
+        ORBX_HIP_TRY(hipMemcpyAsync(F.desc.p, srcD, (size_t)n * 32, kind, st));
+        if (uright) ORBX_HIP_TRY(hipMemcpyAsync(F.uright.p, srcU, (size_t)n * 4, kind, st));
         F.hostUright.resize(uright ? (size_t)n : 0);
         if (uright && fromDevice) ORBX_HIP_TRY(hipMemcpyAsync(F.hostUright.data(), uright, (size_t)n * 4, hipMemcpyDeviceToHost, st));
         else if (uright) memcpy(F.hostUright.data(), uright, (size_t)n * 4);
