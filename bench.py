@@ -50,6 +50,12 @@ HBM_PEAK_GBS = 8000.0                                     # MI355X HBM3E spec
 VALU_U32_PEAK = 256 * 4 * 32 * 2.4e9                      # lane-ops/s (256 CU x 4 SIMD x 32 lanes x 2.4 GHz), nominal
 VALU_XOR_BCNT_MEASURED = 49.4e12                          # lane-ops/s of the search's own instruction pair, measured
 NQ_MAP, NT_MAP = 5000, 10_000_000
+# Rehearsal of the N > 1 control flow on a machine with ONE GPU (tests/test_gpu_bench_rehearsal.py): every rank uses
+# device 0 and the collectives run over gloo on host copies (RCCL refuses two ranks on one device).  The numbers of such
+# a run mean nothing; what it shows is that the ranks go through the same barriers, reductions and the gather + merge
+# of the sharded search with matching shapes.  ORBX_BENCH_NT_MAP shrinks the map for it.
+REHEARSE = os.environ.get("ORBX_BENCH_REHEARSE") == "1"
+NT_MAP = int(os.environ.get("ORBX_BENCH_NT_MAP", NT_MAP))
 
 
 def level_pixels(ex):
@@ -252,10 +258,34 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    if REHEARSE:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if REHEARSE:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def max_over_ranks(x):
+        """The largest x of all ranks (x itself in a single-process run)."""
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if REHEARSE else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather_rows(dst, part):
+        """dst [world * n, 4] = the ranks' part [n, 4] in rank order."""
+        if not REHEARSE:
+            dist.all_gather_into_tensor(dst, part)
+            return
+        torch.cuda.synchronize()
+        mine = part.cpu()
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        dst.copy_(torch.cat(parts).to(dst.device))
 
     import orb_slam3_amd as A
     from orb_slam3_amd import synth
@@ -418,10 +448,7 @@ def main():
         batch_step(i)
         torch.cuda.synchronize()
     dt_serial = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt)
     # The same K steps once more with a HIP event recorded on the launch stream between the
     # kernels: per-kernel spans while the other camera's kernels share the GPU.  (Each event costs a few
     # microseconds of pipeline bubble, which is why `value` comes from the pass above; under contention a span
@@ -523,6 +550,8 @@ def main():
         "value_one_batch_at_a_time": frames_per_batch * n_serial / dt_serial,
     }
 
+    if REHEARSE:
+        out["rehearsal"] = "N > 1 control flow rehearsed on one GPU over gloo: the numbers of this line are not measurements"
     if valu is not None:
         valu["frac_of_ceiling"] = value / world / valu["ceiling_frames_per_s"]
         out["issue_bound"] = valu
@@ -574,11 +603,7 @@ def main():
             d = time.perf_counter() - t0
             for e in exs:
                 e.status()
-            if world > 1:
-                t = torch.tensor([d], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                d = float(t.item())
-            return d
+            return max_over_ranks(d)
         launches1 = max(2, (launches // 4) & ~1)
         dth1 = run(1, launches1)
         dth = run(NH, launches)
@@ -627,7 +652,7 @@ def main():
             nonlocal ws
             p, ws = A.knn_match2_device(dq, dt_map, base_index=base, out=part, workspace=ws)
             if world > 1:
-                dist.all_gather_into_tensor(gathered, p)
+                gather_rows(gathered, p)
                 return A.knn2_merge_device(gathered.view(world, NQ_MAP, 4))
             return p
         search(); torch.cuda.synchronize(); barrier()
@@ -640,10 +665,7 @@ def main():
         ev1.record()
         torch.cuda.synchronize(); barrier()
         th = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([th], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            th = float(t.item())
+        th = max_over_ranks(th)
         per = th / iters
         pairs_s = NQ_MAP * NT_MAP / per
         # outside the timed region: the result of the last search is checked by recomputing every reported distance
