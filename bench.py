@@ -340,7 +340,7 @@ def main():
         bhd, linkhd, nkhd = batched_rate(1920, 1080, 5000, 64, 12, 70, 32)
         host_path = {"what": "orbx_extract / orbx_extract_batch through the ctypes mirror: pageable images in, keypoints and "
                              "descriptors in host memory out (staging copy + H2D + kernels + D2H + copy out + synchronisation); "
-                             "batches of 40 MB of images or more run as a pipeline of chunks on three streams with the staging "
+                             "batches of 20 MB of images or more run as a pipeline of chunks on three streams with the staging "
                              "copies on three helper threads; the batch legs pass a stack of images (64 / 64 / 32 distinct "
                              "scenes) and receive whole arrays",
                      "orbx_extract_frames_per_s": single, "orbx_extract_windows_frames_per_s": windows,

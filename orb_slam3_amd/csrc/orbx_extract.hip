@@ -2687,10 +2687,15 @@ static orbx_status extract_host(orbx_extractor* ex, const uint8_t* const* images
     s = ensure_host_staging(ex);
     if (s != ORBX_OK) return s;
     const size_t frameBytes = (size_t)width * height;
-    // 40 MB of images or more (measured on MI355X / PCIe 5: 111 frames of 752 x 480, 20 of 1920 x 1080; below that the
-    // single captured sequence is as fast): overlap staging, upload, kernels and download.  Rectangles and per-kernel
-    // timing keep the single-sequence path below.
-    if (ndyn == 0 && !ex->timing && n_frames >= 12 && (size_t)n_frames * frameBytes >= ((size_t)40 << 20) &&
+    // 20 MB of images or more (measured on MI355X / PCIe 5, 752 x 480 frames per call, single sequence against pipeline:
+    // 48 frames 46.7 k against 36 k frames/s, 64 frames 47.8 k against 54 k, 96 frames 48.2 k against 64 k -- the pipeline
+    // has about a millisecond of start-up in its helper threads): overlap staging, upload, kernels and download.
+    // Rectangles and per-kernel timing keep the single-sequence path below.  (ORBX_HOST_PIPELINE_MIN_MB moves the limit.)
+    static const size_t pipelineMinBytes = [] {
+        const char* v = getenv("ORBX_HOST_PIPELINE_MIN_MB");
+        return (size_t)(v ? std::max(1, atoi(v)) : 20) << 20;
+    }();
+    if (ndyn == 0 && !ex->timing && n_frames >= 12 && (size_t)n_frames * frameBytes >= pipelineMinBytes &&
         !getenv("ORBX_HOST_NO_PIPELINE"))
         return extract_host_pipelined(ex, images, n_frames, width, height, stride, lap0, lap1, keypoints, descriptors, capacity,
                                       n_out, mono_index_out);
